@@ -1,0 +1,193 @@
+/*
+ * rt_abi.h - C ABI of librt_amd.so, the MI355X (gfx950, HIP) replacement for the
+ * reference renderer's Vulkan compute dispatch of raytrace.comp.
+ *
+ * The reference has no plugin/FFI layer: its ray tracer sits behind private
+ * methods of HardwareRenderer. The boundary reproduced here is the Vulkan
+ * binding contract between that class and its shader: two W x H rgba32f storage
+ * images, 18 storage buffers, one 144-byte push-constant block, one dispatch per
+ * frame. Each export names the reference call site it replaces.
+ *
+ * Conventions: every function returns RT_OK (0) or a negative rt_status; no C++
+ * exception crosses the ABI; rt_last_error() gives the text of the last failure
+ * on that context (or of the last context-less failure when ctx is NULL).
+ * One rt_ctx is externally synchronised (not re-entrant), like the reference's
+ * single render thread; distinct contexts are independent. All device work of a
+ * context is enqueued on one HIP stream; calls that hand data back to the host
+ * (rt_read_image, rt_frame_stats_*) synchronise that stream themselves.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rt_scene rt_scene;
+
+typedef enum rt_status {
+    RT_OK                 = 0,
+    RT_ERR_INVALID_ARG    = -1,
+    RT_ERR_NO_DEVICE      = -2,
+    RT_ERR_HIP            = -3,
+    RT_ERR_NO_SCENE       = -4,
+    RT_ERR_NO_IMAGES      = -5,
+    RT_ERR_SCENE_INVALID  = -6,
+    RT_ERR_IO             = -7,
+    RT_ERR_UNSUPPORTED    = -8
+} rt_status;
+
+enum { RT_IMAGE_DRAW = 0, RT_IMAGE_ACCUM = 1 };
+
+/* Options for rt_set_option. */
+enum {
+    /* 0 = strict IEEE f32 arithmetic, no fused multiply-add (the flavour that is
+     * compared value-for-value with the CPU oracle); 1 = same algorithm with FMA
+     * contraction allowed. Default 0. */
+    RT_OPT_FAST_MATH   = 1,
+    /* 0 = megakernel (one lane walks a whole pixel); 1 = wavefront pipeline
+     * (generate / extend / shade kernels over compacted ray queues). Default 0. */
+    RT_OPT_PIPELINE    = 2,
+    /* Tile partition for multi-GPU tile split: this context renders only the
+     * tiles t with t % RT_OPT_TILE_WORLD == RT_OPT_TILE_RANK (tiles are
+     * RT_OPT_TILE_SIZE x RT_OPT_TILE_SIZE pixels, numbered row-major). Pixels of
+     * other tiles are left untouched. Defaults: rank 0, world 1, size 64. */
+    RT_OPT_TILE_RANK   = 3,
+    RT_OPT_TILE_WORLD  = 4,
+    RT_OPT_TILE_SIZE   = 5
+};
+
+/* ---- device context ------------------------------------------------------ */
+
+/* Replaces InitializeVulkan's device/queue/pipeline bring-up
+ * (HardwareRenderer.cpp:28-129,441-472). device_id is a HIP device ordinal. */
+int rt_create(int device_id, rt_ctx** out_ctx);
+void rt_destroy(rt_ctx* ctx);
+
+/* Use an existing HIP stream (hipStream_t passed as void*) instead of the
+ * context's own; NULL restores the context's stream. */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+
+int rt_set_option(rt_ctx* ctx, int option, int value);
+int rt_get_option(rt_ctx* ctx, int option, int* value);
+
+/* Replaces BufferSceneData / RebufferSceneData (HardwareRenderer.cpp:651-771,
+ * 787-791): takes the 18 host arrays exactly as the reference uploads them,
+ * validates them, re-lays them out for the GPU and copies them to HBM. The
+ * library copies; the caller may free its arrays after return. Re-callable. */
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* buffers);
+
+/* Replaces InitializeSwapchain / RecreateSwapchain image creation
+ * (HardwareRenderer.cpp:131-158,232-245): (re)allocates the W x H rgba32f draw
+ * and accumulation images and clears both. */
+int rt_resize(rt_ctx* ctx, int width, int height);
+
+/* Same, but renders into caller-owned device memory (two W*H*16-byte buffers,
+ * row 0 = top row). Nothing is cleared. Pass NULLs to return to owned images. */
+int rt_bind_images(rt_ctx* ctx, void* draw_dev, void* accum_dev, int width, int height);
+
+/* Replaces RefreshAccumulation (HardwareRenderer.cpp:840-848): zero the
+ * accumulation image (all four channels). The caller owns the frame counter. */
+int rt_clear_accumulation(rt_ctx* ctx);
+
+/* Replaces DispatchRayTracingCommands' vkCmdPushConstants + vkCmdDispatch
+ * (HardwareRenderer.cpp:833-837): one dispatch of the shader's main() over every
+ * pixel with these push constants. Asynchronous on the context's stream. */
+int rt_render_frame(rt_ctx* ctx, const rt_push_constants* pc);
+
+/* Replaces ProduceRender's loop (HardwareRenderer.cpp:1039-1043): `count`
+ * dispatches with pc->frame = first_frame, first_frame + stride, ... A stride
+ * above 1 is the sample split used across GPUs (rank r renders frames r, r+N..). */
+int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc,
+                     int first_frame, int stride, int count);
+
+/* Replaces the per-frame vkDeviceWaitIdle (HardwareRenderer.cpp:969). */
+int rt_sync(rt_ctx* ctx);
+
+/* Replaces WriteDrawImageToFile's image->staging copy (HardwareRenderer.cpp:
+ * 1063-1104): tightly packed row-major RGBA f32, row 0 = top. `bytes` must be
+ * exactly W*H*16. Synchronises. */
+int rt_read_image(rt_ctx* ctx, int which, float* dst_rgba, size_t bytes);
+
+/* Loads an accumulation image (resume, or a merged multi-GPU sum). */
+int rt_write_accum(rt_ctx* ctx, const float* src_rgba, size_t bytes);
+
+/* draw = gamma(accum.rgb * 1/total_frames), draw.a = accum.a: the output half of
+ * Pathtrace (raytrace.comp:794-801) applied to an accumulation image that was
+ * merged from several GPUs. */
+int rt_resolve(rt_ctx* ctx, int total_frames);
+
+/* Runs the same dispatch as rt_render_frame on a counting build of the kernel
+ * that writes no image and returns the work counters summed over all pixels
+ * (the shader's bvhNodeTests/triangleTests in reference traversal order, plus
+ * the number of GetHit calls). Synchronises. */
+int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out);
+
+/* Milliseconds the last rt_render_frame(s) call spent on the device, measured
+ * with HIP events on the stream the kernels were launched on. Synchronises. */
+int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_dispatch);
+
+int rt_image_size(rt_ctx* ctx, int* width, int* height);
+const char* rt_last_error(rt_ctx* ctx);
+const char* rt_version(void);
+
+/* ---- host helpers that restate the reference's CPU-side feeders ------------ */
+
+/* Camera -> push constants, the arithmetic of DispatchRayTracingCommands
+ * (HardwareRenderer.cpp:795-824). Fills pixel00Location, pixelDeltaU/V,
+ * cameraPosition, defocusAngle, defocusDiskU/V; leaves every other field. */
+int rt_camera_to_push_constants(const rt_camera_settings* cam, int width, int height,
+                                rt_push_constants* pc);
+
+/* Default-initialised push constants / camera / material
+ * (RaytracerTypes.h:22-52,127-138, HardwareRenderer.h:68-75). */
+void rt_default_push_constants(rt_push_constants* pc);
+void rt_default_camera(rt_camera_settings* cam);
+void rt_default_material(rt_gpu_material* m);
+
+/* Scene builder with the semantics of HardwareRenderer's scene half. */
+rt_scene* rt_scene_create(void);
+void rt_scene_destroy(rt_scene* s);
+const char* rt_scene_last_error(rt_scene* s);
+
+/* m_sceneMaterials.push_back (HardwareRenderer.cpp:576-627). Returns the index. */
+int rt_scene_add_material(rt_scene* s, const rt_gpu_material* m);
+/* GetMaterialIndex (HardwareRenderer.cpp:479-488): first equal material or -1. */
+int rt_scene_material_index(rt_scene* s, const rt_gpu_material* m);
+/* LoadModel (HardwareRenderer.cpp:1157-1314): OBJ -> triangles -> midpoint BVH,
+ * appended to the global arrays; cached by path. */
+int rt_scene_load_model(rt_scene* s, const char* obj_path);
+/* AddSceneObject (HardwareRenderer.cpp:490-500); rotation in degrees.
+ * Returns the object index. */
+int rt_scene_add_object(rt_scene* s, const char* model_path, const float position[3],
+                        const float rotation_deg[3], const float scale[3],
+                        const rt_gpu_material* material);
+/* Scene-editor edits (SceneEditorUI.hpp:23-97). */
+int rt_scene_set_object(rt_scene* s, int index, const float position[3],
+                        const float rotation_deg[3], const float scale[3], int material_index);
+int rt_scene_set_material(rt_scene* s, int index, const rt_gpu_material* m);
+/* BufferSceneData's CPU half (HardwareRenderer.cpp:653-657): run
+ * ConvertSceneObjectToGPUObject over every object, rebuilding the parent/object
+ * arrays. Must be called before rt_scene_get_buffers. */
+int rt_scene_buffer_data(rt_scene* s);
+/* Views into the scene's arrays (valid until the scene is modified/destroyed). */
+int rt_scene_get_buffers(rt_scene* s, rt_scene_buffers* out);
+/* InitializeScene (HardwareRenderer.cpp:574-649): 9 materials, 3 models, 8
+ * objects. models_dir holds flat_quad.obj, icosphere.obj and dragon_file (the
+ * reference names dragon.obj; that file is not distributed, dragon_lowres.obj is). */
+int rt_scene_init_default(rt_scene* s, const char* models_dir, const char* dragon_file);
+/* Per-model structure facts: triangles, BVH nodes (excluding the parent), depth. */
+int rt_scene_model_info(rt_scene* s, const char* model_path, int* triangles, int* nodes,
+                        int* max_depth, int* max_leaf);
+
+/* WriteDrawImageToFile's float -> 8-bit conversion (HardwareRenderer.cpp:1099-
+ * 1125): clamp to [0,1], x*255+0.5 truncated, alpha forced to 255. */
+void rt_rgba32f_to_rgba8(const float* src, uint8_t* dst, size_t pixel_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */
