@@ -1,0 +1,14 @@
+"""raytracer_amd - Python access to librt_amd.so, the MI355X (gfx950) implementation of
+the reference renderer's per-pixel path-tracing dispatch.
+
+The package is a thin ctypes layer over the C ABI declared in include/rt_abi.h; all
+rendering happens in hand-written HIP kernels inside the shared library. There is no
+Python or CPU rendering path: if the library is missing, or no HIP device is present,
+the calls raise.
+"""
+from .api import (  # noqa: F401
+    LIB_PATH, MODELS_DIR, PushConstants, CameraSettings, Material, FrameStats, SceneBuffers, RtError,
+    load_library, Scene, Renderer, default_push_constants, default_camera, camera_to_push_constants,
+    rgba32f_to_rgba8, RT_IMAGE_DRAW, RT_IMAGE_ACCUM, RT_OPT_FAST_MATH, RT_OPT_PIPELINE, RT_OPT_TILE_RANK,
+    RT_OPT_TILE_WORLD, RT_OPT_TILE_SIZE,
+)

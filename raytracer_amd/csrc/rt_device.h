@@ -1,0 +1,88 @@
+// rt_device.h - device-side scene layout shared by the host re-layout code
+// (rt_host.cpp) and the gfx950 kernels (rt_kernels.hip).
+//
+// The reference shader reads 18 separate storage buffers (raytrace.comp:83-171).
+// For the GPU they are re-laid out at upload time into five arrays:
+//
+//  DevObject  one per ParentBVHNode, in scene order (wave-uniform reads, so the
+//             compiler fetches them with scalar loads): world box, the 3x4 part
+//             of inverseTransform, the 3x4 part of its inverse (the shader's
+//             per-ray `inverse(mat4)`, raytrace.comp:485, hoisted to upload
+//             time with the same arithmetic), material, root reference.
+//  DevNode    one 64-byte record per *inner* BVH node holding BOTH children's
+//             boxes and references, so that one node visit is one aligned
+//             64-byte fetch instead of two dependent 40-byte visits.
+//             `first` is the child the reference pops first: the LEFT child of
+//             an inner node (raytrace.comp:603-604) but the RIGHT child of a
+//             ParentBVHNode (raytrace.comp:525-526).
+//  DevTri     48 bytes per triangle in leaf order: v0, edge1 = v1-v0,
+//             edge2 = v2-v0 (raytrace.comp:288-289 hoisted), plus the number of
+//             triangles left in the leaf and the original triangle index.
+//  DevNrm     48 bytes per original triangle: the three vertex normals, read
+//             only for the one winning hit of a GetHit call.
+//  materials  GPUMaterial verbatim.
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <stdint.h>
+
+#define RT_REF_ABSENT ((int32_t)0x80000000)      /* child index was -1: not counted, not visited */
+#define RT_REF_EMPTY  ((int32_t)0x80000001)      /* leaf with zero triangles: counted, nothing to test */
+#define RT_MAX_STACK  32                         /* the shader's `int stack[32]` (raytrace.comp:523) */
+
+struct DevObject {
+    float   bmin[3];
+    int32_t root;          /* >=0: DevNode index; <0: leaf, ~root = first DevTri; or RT_REF_EMPTY */
+    float   bmax[3];
+    int32_t materialIndex;
+    float   inv[12];       /* inverseTransform, row r = inv[4r..4r+3] = (c0r,c1r,c2r,c3r) */
+    float   fwd[12];       /* inverse(inverseTransform), same row layout */
+};
+
+struct DevNode {
+    float   fmin[3], fmax[3];   /* box of the child visited first */
+    float   smin[3], smax[3];   /* box of the child visited second */
+    int32_t first;              /* >=0 DevNode, <0 leaf (~first = DevTri index), RT_REF_ABSENT / RT_REF_EMPTY */
+    int32_t second;
+    int32_t pad[2];
+};
+
+struct DevTri {
+    float   v0[3];  int32_t remaining;  /* triangles left in this leaf including this one */
+    float   e1[3];  int32_t orig;       /* index into the caller's triangle arrays (and DevNrm) */
+    float   e2[3];  int32_t pad;
+};
+
+struct DevNrm {
+    float n0[4], n1[4], n2[4];
+};
+
+struct DevMaterial {   /* GPUMaterial, RaytracerTypes.h:127-138 */
+    float colour[3]; float smoothness;
+    float fuzziness; float emission; float refractionIndex; float pad1;
+    float absorbtion[3]; float pad3;
+};
+
+struct DevScene {
+    const DevObject*   objects;
+    const DevNode*     nodes;
+    const DevTri*      tris;
+    const DevNrm*      nrms;
+    const DevMaterial* materials;
+    int32_t            objectCount;   /* number of DevObject records uploaded */
+    int32_t            stackDepth;    /* entries of traversal stack a lane can need (<= RT_MAX_STACK) */
+};
+
+struct DevLaunch {
+    int32_t width, height;
+    int32_t tileSize;      /* partition tile edge in pixels, multiple of 8 */
+    int32_t tilesX, tilesY;
+    int32_t tileRank, tileWorld;
+    int32_t ownedTiles;    /* number of tiles t with t % tileWorld == tileRank */
+};
+
+struct DevCounters {
+    unsigned long long rays, nodeTests, triTests, samples;
+};
+
+#endif

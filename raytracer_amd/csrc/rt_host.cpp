@@ -1,0 +1,624 @@
+// rt_host.cpp - the C-ABI device layer of librt_amd.so: what replaces the
+// reference's Vulkan plumbing around its ray-tracing dispatch
+// (src/Renderers/Hardware/HardwareRenderer.cpp: BufferSceneData :651-771,
+// swapchain image creation :131-158, RefreshAccumulation :840-848,
+// DispatchRayTracingCommands :793-838, WriteDrawImageToFile :1063-1104).
+//
+// It validates the 18 reference-layout arrays, re-lays them out for the GPU
+// (rt_device.h), keeps them resident in HBM, and launches the gfx950 kernels of
+// rt_kernels.hip on one HIP stream per context. There is no CPU rendering path:
+// without a HIP device every entry point that needs one fails with
+// RT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "rt_device.h"
+
+void rt_mat4_inverse(const float in[16], float out[16]);   // rt_scene.cpp
+
+extern "C" {
+hipError_t rt_launch_megakernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
+                                       DevCounters*, int, int, hipStream_t);
+hipError_t rt_launch_megakernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
+                                     DevCounters*, int, int, hipStream_t);
+hipError_t rt_launch_resolve_strict(const void*, void*, size_t, float, hipStream_t);
+hipError_t rt_launch_resolve_fast(const void*, void*, size_t, float, hipStream_t);
+}
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool timed = false;
+    int lastDispatches = 0;
+
+    // scene in HBM
+    DevScene scene{};
+    void* dObjects = nullptr;
+    void* dNodes = nullptr;
+    void* dTris = nullptr;
+    void* dNrms = nullptr;
+    void* dMaterials = nullptr;
+    bool haveScene = false;
+    size_t sceneBytes = 0;
+
+    // images
+    int width = 0, height = 0;
+    void* ownDraw = nullptr;
+    void* ownAccum = nullptr;
+    void* draw = nullptr;
+    void* accum = nullptr;
+
+    DevCounters* dCounters = nullptr;
+
+    int optFast = 0, optPipeline = 0, tileRank = 0, tileWorld = 1, tileSize = 64;
+    std::string error;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(rt_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->error = msg;
+    g_error = msg;
+    return code;
+}
+
+int failHip(rt_ctx* ctx, hipError_t e, const char* what)
+{
+    return fail(ctx, RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define RT_HIP(ctx, call)                                         \
+    do {                                                          \
+        hipError_t e_ = (call);                                   \
+        if (e_ != hipSuccess) return failHip(ctx, e_, #call);     \
+    } while (0)
+
+void freeScene(rt_ctx* c)
+{
+    for (void** p : { &c->dObjects, &c->dNodes, &c->dTris, &c->dNrms, &c->dMaterials }) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    c->haveScene = false;
+    c->sceneBytes = 0;
+}
+
+void freeImages(rt_ctx* c)
+{
+    if (c->ownDraw) (void)hipFree(c->ownDraw);
+    if (c->ownAccum) (void)hipFree(c->ownAccum);
+    c->ownDraw = c->ownAccum = nullptr;
+}
+
+struct Float4 { float x, y, z, w; };
+
+// Host-side builder of the device layout.
+struct Relayout {
+    const rt_scene_buffers& in;
+    const rt_parent_bvh_node* parents;
+    const rt_gpu_object* objects;
+    const Float4 *v0, *v1, *v2;
+    const Float4 *bmin, *bmax;
+    const int32_t *left, *right, *triStart, *triCount;
+    size_t nodeCount, triCountTotal;
+
+    std::vector<DevObject> dObjects;
+    std::vector<DevNode> dNodes;
+    std::vector<DevTri> dTris;
+    std::map<std::pair<int, int>, int32_t> leafMemo;    // (triStart, count) -> ref
+    std::map<std::pair<int, int>, int32_t> nodeMemo;    // (first child, second child) -> DevNode index
+    std::vector<int> nodeHeight;                        // per DevNode; -1 while being built
+    int maxDepth = 0;
+    std::string error;
+
+    explicit Relayout(const rt_scene_buffers& b) : in(b)
+    {
+        parents = static_cast<const rt_parent_bvh_node*>(b.parentBVH.data);
+        objects = static_cast<const rt_gpu_object*>(b.objects.data);
+        v0 = static_cast<const Float4*>(b.triangleV0s.data);
+        v1 = static_cast<const Float4*>(b.triangleV1s.data);
+        v2 = static_cast<const Float4*>(b.triangleV2s.data);
+        bmin = static_cast<const Float4*>(b.aabbMins.data);
+        bmax = static_cast<const Float4*>(b.aabbMaxs.data);
+        left = static_cast<const int32_t*>(b.bvhNodeLeftChildren.data);
+        right = static_cast<const int32_t*>(b.bvhNodeRightChildren.data);
+        triStart = static_cast<const int32_t*>(b.bvhNodeTriangleStartIndices.data);
+        triCount = static_cast<const int32_t*>(b.bvhNodeTriangleCounts.data);
+        nodeCount = b.aabbMins.count;
+        triCountTotal = b.triangleV0s.count;
+    }
+
+    bool leafRef(int start, int count, int32_t& ref)
+    {
+        if (count <= 0) { ref = RT_REF_EMPTY; return true; }
+        if (start < 0 || (size_t)start + (size_t)count > triCountTotal) {
+            error = "leaf triangle range [" + std::to_string(start) + ", +" + std::to_string(count) + ") is outside the triangle arrays";
+            return false;
+        }
+        auto key = std::make_pair(start, count);
+        auto it = leafMemo.find(key);
+        if (it != leafMemo.end()) { ref = it->second; return true; }
+        const size_t base = dTris.size();
+        if (base + (size_t)count >= 0x7ffffff0u) { error = "too many triangles"; return false; }
+        for (int j = 0; j < count; ++j) {
+            const Float4 a = v0[start + j], b = v1[start + j], c = v2[start + j];
+            DevTri t{};
+            t.v0[0] = a.x; t.v0[1] = a.y; t.v0[2] = a.z;
+            t.e1[0] = b.x - a.x; t.e1[1] = b.y - a.y; t.e1[2] = b.z - a.z;   // raytrace.comp:288
+            t.e2[0] = c.x - a.x; t.e2[1] = c.y - a.y; t.e2[2] = c.z - a.z;   // raytrace.comp:289
+            t.remaining = count - j;
+            t.orig = start + j;
+            dTris.push_back(t);
+        }
+        ref = ~(int32_t)base;
+        leafMemo[key] = ref;
+        return true;
+    }
+
+    // Reference for BVH node `n` as seen from its parent record. `height` receives
+    // the number of two-child records on the longest path below (0 for a leaf).
+    bool childRef(int n, int depth, int32_t& ref, int& height)
+    {
+        height = 0;
+        if (n == -1) { ref = RT_REF_ABSENT; return true; }
+        if (n < 0 || (size_t)n >= nodeCount) { error = "child index " + std::to_string(n) + " is outside the node arrays"; return false; }
+        const int l = left[n], r = right[n];
+        if (l == -1 && r == -1) return leafRef(triStart[n], triCount[n], ref);
+        return innerRef(l, r, depth, ref, height);   // the shader pushes right then left: left is popped first
+    }
+
+    // Two-child record whose `first` child is visited first. `depth` counts the
+    // records on the path from the object root down to and including this one;
+    // it bounds the traversal stack a lane can need.
+    bool innerRef(int first, int second, int depth, int32_t& ref, int& height)
+    {
+        const char* tooDeep = "BVH deeper than 31 levels: the shader's int stack[32] would overflow";
+        if (depth > RT_MAX_STACK - 1) { error = tooDeep; return false; }
+        auto key = std::make_pair(first, second);
+        auto it = nodeMemo.find(key);
+        if (it != nodeMemo.end()) {
+            if (nodeHeight[it->second] < 0) { error = "the BVH child indices form a cycle"; return false; }
+            ref = it->second;
+            height = nodeHeight[ref];
+            if (depth - 1 + height > RT_MAX_STACK - 1) { error = tooDeep; return false; }
+            maxDepth = std::max(maxDepth, depth - 1 + height);
+            return true;
+        }
+        const int32_t idx = (int32_t)dNodes.size();
+        dNodes.push_back(DevNode{});
+        nodeHeight.push_back(-1);   // in progress
+        nodeMemo[key] = idx;
+        maxDepth = std::max(maxDepth, depth);
+        int32_t fr, sr;
+        int hf, hs;
+        if (!childRef(first, depth + 1, fr, hf)) return false;
+        if (!childRef(second, depth + 1, sr, hs)) return false;
+        DevNode n{};
+        auto box = [&](int node, float mn[3], float mx[3]) {
+            if (node == -1) { mn[0] = mn[1] = mn[2] = 0.0f; mx[0] = mx[1] = mx[2] = 0.0f; return; }
+            mn[0] = bmin[node].x; mn[1] = bmin[node].y; mn[2] = bmin[node].z;
+            mx[0] = bmax[node].x; mx[1] = bmax[node].y; mx[2] = bmax[node].z;
+        };
+        box(first, n.fmin, n.fmax);
+        box(second, n.smin, n.smax);
+        n.first = fr;
+        n.second = sr;
+        dNodes[idx] = n;
+        height = 1 + std::max(hf, hs);
+        nodeHeight[idx] = height;
+        ref = idx;
+        return true;
+    }
+
+    bool run()
+    {
+        const size_t P = in.parentBVH.count;
+        dObjects.resize(P);
+        for (size_t i = 0; i < P; ++i) {
+            const rt_parent_bvh_node& p = parents[i];
+            if (p.objectIndex < 0 || (size_t)p.objectIndex >= in.objects.count) {
+                error = "parentBVH[" + std::to_string(i) + "].objectIndex out of range";
+                return false;
+            }
+            const rt_gpu_object& o = objects[p.objectIndex];
+            if (o.materialIndex < 0 || (size_t)o.materialIndex >= in.materials.count) {
+                error = "object " + std::to_string(p.objectIndex) + " has material index " + std::to_string(o.materialIndex) +
+                        " outside the material array";
+                return false;
+            }
+            DevObject d{};
+            for (int a = 0; a < 3; ++a) { d.bmin[a] = p.node.aabb.min[a]; d.bmax[a] = p.node.aabb.max[a]; }
+            d.materialIndex = o.materialIndex;
+            float fwd[16];
+            rt_mat4_inverse(o.inverseTransform, fwd);   // raytrace.comp:485, hoisted
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 4; ++c) {
+                    d.inv[4 * r + c] = o.inverseTransform[4 * c + r];
+                    d.fwd[4 * r + c] = fwd[4 * c + r];
+                }
+            if (p.node.leftChild == -1 && p.node.rightChild == -1) {
+                if (!leafRef(p.node.triangleStartIndex, p.node.triangleCount, d.root)) return false;
+            } else {
+                // raytrace.comp:525-526 pushes left then right, so the RIGHT child is popped first
+                int h;
+                if (!innerRef(p.node.rightChild, p.node.leftChild, 1, d.root, h)) return false;
+            }
+            dObjects[i] = d;
+        }
+        return true;
+    }
+};
+
+int uploadArray(rt_ctx* ctx, void** dst, const void* src, size_t bytes)
+{
+    *dst = nullptr;
+    const size_t alloc = std::max<size_t>(bytes, 256);
+    RT_HIP(ctx, hipMalloc(dst, alloc));
+    RT_HIP(ctx, hipMemsetAsync(*dst, 0, alloc, ctx->stream));
+    if (bytes) RT_HIP(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return RT_OK;
+}
+
+DevLaunch makeLaunch(const rt_ctx* c)
+{
+    DevLaunch L{};
+    L.width = c->width;
+    L.height = c->height;
+    L.tileSize = c->tileSize;
+    L.tilesX = (c->width + c->tileSize - 1) / c->tileSize;
+    L.tilesY = (c->height + c->tileSize - 1) / c->tileSize;
+    L.tileRank = c->tileRank;
+    L.tileWorld = c->tileWorld;
+    const int total = L.tilesX * L.tilesY;
+    L.ownedTiles = total > c->tileRank ? (total - c->tileRank + c->tileWorld - 1) / c->tileWorld : 0;
+    return L;
+}
+
+int checkRenderable(rt_ctx* ctx, const rt_push_constants* pc)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!pc) return fail(ctx, RT_ERR_INVALID_ARG, "null push constants");
+    if (!ctx->haveScene) return fail(ctx, RT_ERR_NO_SCENE, "no scene uploaded (call rt_upload_scene first)");
+    if (!ctx->draw || !ctx->accum) return fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
+    if (pc->parentBVHCount < 0 || pc->parentBVHCount > ctx->scene.objectCount)
+        return fail(ctx, RT_ERR_INVALID_ARG, "parentBVHCount " + std::to_string(pc->parentBVHCount) + " exceeds the " +
+                                                 std::to_string(ctx->scene.objectCount) + " uploaded parent nodes");
+    if (pc->renderMode == 0 || pc->renderMode == 3 || pc->renderMode == 4) {
+        if (pc->raysPerPixel < 0) return fail(ctx, RT_ERR_INVALID_ARG, "raysPerPixel is negative");
+    }
+    if (ctx->optPipeline != 0) return fail(ctx, RT_ERR_UNSUPPORTED, "the wavefront pipeline is not built into this library");
+    return RT_OK;
+}
+
+int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly)
+{
+    const DevLaunch L = makeLaunch(ctx);
+    const bool countBuild = statsOnly || pc.renderMode == 3 || pc.renderMode == 4;
+    auto fn = ctx->optFast ? rt_launch_megakernel_fast : rt_launch_megakernel_strict;
+    hipError_t e = fn(&ctx->scene, &pc, &L, ctx->accum, ctx->draw, statsOnly ? ctx->dCounters : nullptr, countBuild ? 1 : 0,
+                      statsOnly ? 1 : 0, ctx->stream);
+    if (e != hipSuccess) return failHip(ctx, e, "kernel launch");
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rt_version(void) { return "rt_amd 0.1 (gfx950)"; }
+
+const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+int rt_create(int device_id, rt_ctx** out_ctx)
+{
+    if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: null out pointer");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device available: this library has no CPU path");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_INVALID_ARG, "device ordinal out of range");
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) return fail(nullptr, RT_ERR_HIP, "out of host memory");
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
+        (e = hipMalloc((void**)&c->dCounters, sizeof(DevCounters))) != hipSuccess) {
+        int rc = failHip(nullptr, e, "rt_create");
+        rt_destroy(c);
+        return rc;
+    }
+    c->stream = c->ownStream;
+    *out_ctx = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    freeScene(c);
+    freeImages(c);
+    if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+int rt_set_stream(rt_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->ownStream;
+    ctx->timed = false;
+    return RT_OK;
+}
+
+int rt_set_option(rt_ctx* ctx, int option, int value)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    switch (option) {
+    case RT_OPT_FAST_MATH: ctx->optFast = value ? 1 : 0; return RT_OK;
+    case RT_OPT_PIPELINE:
+        if (value != 0) return fail(ctx, RT_ERR_UNSUPPORTED, "only pipeline 0 (megakernel) is available");
+        ctx->optPipeline = 0;
+        return RT_OK;
+    case RT_OPT_TILE_RANK:
+        if (value < 0) return fail(ctx, RT_ERR_INVALID_ARG, "tile rank must be >= 0");
+        ctx->tileRank = value;
+        return RT_OK;
+    case RT_OPT_TILE_WORLD:
+        if (value < 1) return fail(ctx, RT_ERR_INVALID_ARG, "tile world must be >= 1");
+        ctx->tileWorld = value;
+        return RT_OK;
+    case RT_OPT_TILE_SIZE:
+        if (value < 8 || value > 1024 || (value & 7)) return fail(ctx, RT_ERR_INVALID_ARG, "tile size must be a multiple of 8 in [8,1024]");
+        ctx->tileSize = value;
+        return RT_OK;
+    default: return fail(ctx, RT_ERR_INVALID_ARG, "unknown option");
+    }
+}
+
+int rt_get_option(rt_ctx* ctx, int option, int* value)
+{
+    if (!ctx || !value) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");
+    switch (option) {
+    case RT_OPT_FAST_MATH: *value = ctx->optFast; return RT_OK;
+    case RT_OPT_PIPELINE: *value = ctx->optPipeline; return RT_OK;
+    case RT_OPT_TILE_RANK: *value = ctx->tileRank; return RT_OK;
+    case RT_OPT_TILE_WORLD: *value = ctx->tileWorld; return RT_OK;
+    case RT_OPT_TILE_SIZE: *value = ctx->tileSize; return RT_OK;
+    default: return fail(ctx, RT_ERR_INVALID_ARG, "unknown option");
+    }
+}
+
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
+{
+    if (!ctx || !b) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: null argument");
+    // shape checks that must hold before any array is indexed
+    const size_t T = b->triangleV0s.count;
+    for (const rt_buffer_view* v : { &b->triangleV1s, &b->triangleV2s, &b->triangleN0s, &b->triangleN1s, &b->triangleN2s })
+        if (v->count != T) return fail(ctx, RT_ERR_SCENE_INVALID, "the six triangle arrays must have the same length");
+    const size_t N = b->aabbMins.count;
+    for (const rt_buffer_view* v : { &b->aabbMaxs, &b->bvhNodeLeftChildren, &b->bvhNodeRightChildren,
+                                     &b->bvhNodeTriangleStartIndices, &b->bvhNodeTriangleCounts })
+        if (v->count != N) return fail(ctx, RT_ERR_SCENE_INVALID, "the six BVH node arrays must have the same length");
+    for (const rt_buffer_view* v : { &b->parentBVH, &b->objects, &b->materials, &b->triangleV0s, &b->triangleV1s, &b->triangleV2s,
+                                     &b->triangleN0s, &b->triangleN1s, &b->triangleN2s, &b->aabbMins, &b->aabbMaxs,
+                                     &b->bvhNodeLeftChildren, &b->bvhNodeRightChildren, &b->bvhNodeTriangleStartIndices,
+                                     &b->bvhNodeTriangleCounts })
+        if (v->count != 0 && v->data == nullptr) return fail(ctx, RT_ERR_INVALID_ARG, "a non-empty buffer view has a null pointer");
+    if (T >= 0x7ffffff0u || N >= 0x7ffffff0u) return fail(ctx, RT_ERR_SCENE_INVALID, "scene too large for 32-bit indices");
+
+    Relayout rl(*b);
+    if (!rl.run()) return fail(ctx, RT_ERR_SCENE_INVALID, rl.error);
+
+    // normals, verbatim, indexed by original triangle
+    std::vector<DevNrm> nrms(T);
+    const Float4* n0 = static_cast<const Float4*>(b->triangleN0s.data);
+    const Float4* n1 = static_cast<const Float4*>(b->triangleN1s.data);
+    const Float4* n2 = static_cast<const Float4*>(b->triangleN2s.data);
+    for (size_t i = 0; i < T; ++i) {
+        std::memcpy(nrms[i].n0, &n0[i], 16);
+        std::memcpy(nrms[i].n1, &n1[i], 16);
+        std::memcpy(nrms[i].n2, &n2[i], 16);
+    }
+
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    freeScene(ctx);
+    int rc;
+    if ((rc = uploadArray(ctx, &ctx->dObjects, rl.dObjects.data(), rl.dObjects.size() * sizeof(DevObject))) != RT_OK) return rc;
+    if ((rc = uploadArray(ctx, &ctx->dNodes, rl.dNodes.data(), rl.dNodes.size() * sizeof(DevNode))) != RT_OK) return rc;
+    if ((rc = uploadArray(ctx, &ctx->dTris, rl.dTris.data(), rl.dTris.size() * sizeof(DevTri))) != RT_OK) return rc;
+    if ((rc = uploadArray(ctx, &ctx->dNrms, nrms.data(), nrms.size() * sizeof(DevNrm))) != RT_OK) return rc;
+    if ((rc = uploadArray(ctx, &ctx->dMaterials, b->materials.data, b->materials.count * sizeof(DevMaterial))) != RT_OK) return rc;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die at return
+
+    ctx->scene.objects = static_cast<const DevObject*>(ctx->dObjects);
+    ctx->scene.nodes = static_cast<const DevNode*>(ctx->dNodes);
+    ctx->scene.tris = static_cast<const DevTri*>(ctx->dTris);
+    ctx->scene.nrms = static_cast<const DevNrm*>(ctx->dNrms);
+    ctx->scene.materials = static_cast<const DevMaterial*>(ctx->dMaterials);
+    ctx->scene.objectCount = (int32_t)rl.dObjects.size();
+    ctx->scene.stackDepth = std::max(1, std::min(RT_MAX_STACK, rl.maxDepth));
+    ctx->sceneBytes = rl.dObjects.size() * sizeof(DevObject) + rl.dNodes.size() * sizeof(DevNode) + rl.dTris.size() * sizeof(DevTri) +
+                      nrms.size() * sizeof(DevNrm) + b->materials.count * sizeof(DevMaterial);
+    ctx->haveScene = true;
+    return RT_OK;
+}
+
+int rt_resize(rt_ctx* ctx, int width, int height)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (width <= 0 || height <= 0 || width > 65536 || height > 65536) return fail(ctx, RT_ERR_INVALID_ARG, "image size out of range");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    freeImages(ctx);
+    const size_t bytes = (size_t)width * (size_t)height * 16;
+    RT_HIP(ctx, hipMalloc(&ctx->ownDraw, bytes));
+    RT_HIP(ctx, hipMalloc(&ctx->ownAccum, bytes));
+    ctx->draw = ctx->ownDraw;
+    ctx->accum = ctx->ownAccum;
+    ctx->width = width;
+    ctx->height = height;
+    RT_HIP(ctx, hipMemsetAsync(ctx->draw, 0, bytes, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(ctx->accum, 0, bytes, ctx->stream));
+    return RT_OK;
+}
+
+int rt_bind_images(rt_ctx* ctx, void* draw_dev, void* accum_dev, int width, int height)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!draw_dev && !accum_dev) {
+        ctx->draw = ctx->ownDraw;
+        ctx->accum = ctx->ownAccum;
+        if (!ctx->ownDraw) ctx->width = ctx->height = 0;
+        return RT_OK;
+    }
+    if (!draw_dev || !accum_dev || width <= 0 || height <= 0) return fail(ctx, RT_ERR_INVALID_ARG, "rt_bind_images: need both images and a size");
+    if (((uintptr_t)draw_dev & 15) || ((uintptr_t)accum_dev & 15)) return fail(ctx, RT_ERR_INVALID_ARG, "images must be 16-byte aligned");
+    freeImages(ctx);
+    ctx->draw = draw_dev;
+    ctx->accum = accum_dev;
+    ctx->width = width;
+    ctx->height = height;
+    return RT_OK;
+}
+
+int rt_clear_accumulation(rt_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx->accum) return fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemsetAsync(ctx->accum, 0, (size_t)ctx->width * ctx->height * 16, ctx->stream));
+    return RT_OK;
+}
+
+int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, int stride, int count)
+{
+    int rc = checkRenderable(ctx, pc);
+    if (rc != RT_OK) return rc;
+    if (count < 0 || stride < 1) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_frames: count must be >= 0 and stride >= 1");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipEventRecord(ctx->evStart, ctx->stream));
+    rt_push_constants p = *pc;
+    for (int k = 0; k < count; ++k) {
+        p.frame = first_frame + k * stride;
+        if ((rc = launchFrame(ctx, p, false)) != RT_OK) return rc;
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->evStop, ctx->stream));
+    ctx->timed = true;
+    ctx->lastDispatches = count;
+    return RT_OK;
+}
+
+int rt_render_frame(rt_ctx* ctx, const rt_push_constants* pc)
+{
+    if (!pc) return fail(ctx, RT_ERR_INVALID_ARG, "null push constants");
+    return rt_render_frames(ctx, pc, pc->frame, 1, 1);
+}
+
+int rt_sync(rt_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_read_image(rt_ctx* ctx, int which, float* dst, size_t bytes)
+{
+    if (!ctx || !dst) return fail(ctx, RT_ERR_INVALID_ARG, "rt_read_image: null argument");
+    if (!ctx->draw || !ctx->accum) return fail(ctx, RT_ERR_NO_IMAGES, "no images");
+    if (which != RT_IMAGE_DRAW && which != RT_IMAGE_ACCUM) return fail(ctx, RT_ERR_INVALID_ARG, "which must be 0 (draw) or 1 (accum)");
+    const size_t need = (size_t)ctx->width * ctx->height * 16;
+    if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARG, "rt_read_image: bytes must be exactly width*height*16 = " + std::to_string(need));
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemcpyAsync(dst, which == RT_IMAGE_DRAW ? ctx->draw : ctx->accum, need, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_write_accum(rt_ctx* ctx, const float* src, size_t bytes)
+{
+    if (!ctx || !src) return fail(ctx, RT_ERR_INVALID_ARG, "rt_write_accum: null argument");
+    if (!ctx->accum) return fail(ctx, RT_ERR_NO_IMAGES, "no images");
+    const size_t need = (size_t)ctx->width * ctx->height * 16;
+    if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARG, "rt_write_accum: bytes must be exactly width*height*16");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->accum, src, need, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_resolve(rt_ctx* ctx, int total_frames)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx->draw || !ctx->accum) return fail(ctx, RT_ERR_NO_IMAGES, "no images");
+    if (total_frames < 1) return fail(ctx, RT_ERR_INVALID_ARG, "total_frames must be >= 1");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    auto fn = ctx->optFast ? rt_launch_resolve_fast : rt_launch_resolve_strict;
+    hipError_t e = fn(ctx->accum, ctx->draw, (size_t)ctx->width * ctx->height, 1.0f / (float)total_frames, ctx->stream);
+    if (e != hipSuccess) return failHip(ctx, e, "resolve launch");
+    return RT_OK;
+}
+
+int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out)
+{
+    int rc = checkRenderable(ctx, pc);
+    if (rc != RT_OK) return rc;
+    if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "null stats pointer");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemsetAsync(ctx->dCounters, 0, sizeof(DevCounters), ctx->stream));
+    if ((rc = launchFrame(ctx, *pc, true)) != RT_OK) return rc;
+    DevCounters h{};
+    RT_HIP(ctx, hipMemcpyAsync(&h, ctx->dCounters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->rays = h.rays;
+    out->bvhNodeTests = h.nodeTests;
+    out->triangleTests = h.triTests;
+    out->samples = h.samples;
+    return RT_OK;
+}
+
+int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_dispatch)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx->timed) return fail(ctx, RT_ERR_INVALID_ARG, "nothing has been rendered on this stream yet");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipEventSynchronize(ctx->evStop));
+    float ms = 0.0f;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop));
+    if (ms_total) *ms_total = ms;
+    if (ms_per_dispatch) *ms_per_dispatch = ctx->lastDispatches > 0 ? ms / (float)ctx->lastDispatches : 0.0f;
+    return RT_OK;
+}
+
+int rt_image_size(rt_ctx* ctx, int* width, int* height)
+{
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (width) *width = ctx->width;
+    if (height) *height = ctx->height;
+    return RT_OK;
+}
+
+} // extern "C"

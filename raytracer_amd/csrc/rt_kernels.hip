@@ -1,0 +1,668 @@
+// rt_kernels.hip - gfx950 (MI355X) kernels for the per-pixel path-tracing path of
+// the reference renderer: everything its compute shader does in main()
+// (src/Shaders/Compute/raytrace.comp:857-875 and the functions it calls, plus
+// src/Shaders/Compute/Random.glsl), written for 64-wide wavefronts.
+//
+// This file is compiled twice: -DRT_FLAVOUR_STRICT with -ffp-contract=off (plain
+// IEEE binary32, the build that is compared value-for-value with the CPU
+// oracle) and -DRT_FLAVOUR_FAST with FMA contraction allowed.
+//
+// Structure of the megakernel (one lane = one pixel, one wave = one 8x8 tile):
+//   * the object loop of GetHit (raytrace.comp:458) is wave-uniform, so the
+//     per-object record is fetched with scalar loads into SGPRs;
+//   * the per-ray `inverse(mat4)` of raytrace.comp:485 is hoisted to upload time;
+//   * the BVH walk visits 64-byte two-child records: both child boxes are
+//     tested in one visit; the child the reference would pop first is entered
+//     at once, the other is pushed together with its entry distance so that
+//     the reference's pop-time interval test (against the *then current*
+//     closest hit) is reproduced by one compare, without re-reading the box;
+//   * the traversal stack lives in LDS, laid out [depth][lane] (8-byte
+//     entries: conflict-free for any mix of depths across lanes);
+//   * normals are fetched only for the winning triangle of a GetHit call, and
+//     the world-space hit record is rebuilt from (object, triangle, u, v, t)
+//     with the same arithmetic the shader applies at every accepted hit;
+//   * shadow rays stop at the first accepted hit (ShadowTransmission only asks
+//     whether anything was hit, raytrace.comp:612-621). The counting build
+//     (render modes 3/4 and the statistics pass) never stops early, so its
+//     counters are those of the reference traversal.
+// Every floating-point expression keeps the operand order of the GLSL source.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_types.h"
+#include "rt_device.h"
+
+#if defined(RT_FLAVOUR_FAST)
+#define RT_SYM(name) name##_fast
+#else
+#define RT_SYM(name) name##_strict
+#endif
+
+namespace {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b)
+{
+    return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+__device__ __forceinline__ float length3(V3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ V3 normalize3(V3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return a * inv; }
+// GLSL max/min: the second operand wins only on a strict compare.
+__device__ __forceinline__ float gmax(float a, float b) { return a < b ? b : a; }
+__device__ __forceinline__ float gmin(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+__device__ __forceinline__ float gmix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ V3 gmix3(V3 a, V3 b, float t) { return mk(gmix(a.x, b.x, t), gmix(a.y, b.y, t), gmix(a.z, b.z, t)); }
+__device__ __forceinline__ float gpow(float x, float y) { return exp2f(y * log2f(x)); }
+__device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+// ---- Random.glsl ----------------------------------------------------------
+
+// Random.glsl:4-12
+__device__ __forceinline__ float rng_hash(uint32_t& seed)
+{
+    uint32_t s = seed;
+    s = (s ^ 61u) ^ (s >> 16);
+    s *= 9u;
+    s = s ^ (s >> 4);
+    s *= 0x27d4eb2du;
+    s = s ^ (s >> 15);
+    seed = s;
+    return (float)(s % 10000u) / 10000.0f;
+}
+// Random.glsl:28-32
+__device__ __forceinline__ float rng_range(float lo, float hi, uint32_t& seed)
+{
+    seed += 1u;
+    return gmix(lo, hi, rng_hash(seed));
+}
+// Random.glsl:34-41
+__device__ __forceinline__ uint32_t seed_from_coords(uint32_t x, uint32_t y, uint32_t frame, uint32_t i)
+{
+    uint32_t s = x * 374761393u + y * 668265263u + frame * 1442695040u + i * 88963407u;
+    s = (s ^ (s >> 16)) * 0x85ebca6bu;
+    s = (s ^ (s >> 13)) * 0xc2b2ae35u;
+    s = s ^ (s >> 16);
+    return s;
+}
+// Random.glsl:68-78 (with RandomVector :62-66 inlined). 1e-160 reads as 0 in f32.
+__device__ __forceinline__ V3 random_unit_vector(uint32_t& seed)
+{
+    seed += 1u;
+    for (;;) {
+        seed += 1u;
+        float x = rng_range(-1.0f, 1.0f, seed);
+        float y = rng_range(-1.0f, 1.0f, seed);
+        float z = rng_range(-1.0f, 1.0f, seed);
+        V3 p = mk(x, y, z);
+        float len = length3(p);
+        float lensq = len * len;
+        if (0.0f < lensq && lensq <= 1.0f) {
+            float l = sqrtf(lensq);
+            return mk(p.x / l, p.y / l, p.z / l);
+        }
+    }
+}
+// Random.glsl:80-88
+__device__ __forceinline__ V3 random_on_hemisphere(V3 normal, uint32_t& seed)
+{
+    seed += 1u;
+    V3 u = random_unit_vector(seed);
+    return dot3(u, normal) > 0.0f ? u : -u;
+}
+
+// ---- traversal --------------------------------------------------------------
+
+struct Ray { V3 o, d; };
+
+// Per-axis constants of a ray for the slab test of raytrace.comp:205-243:
+// reciprocal, "invD < 0" swap flag, "abs(dir) < 1e-8" parallel flag.
+struct SlabRay {
+    V3 o, inv;
+    bool negx, negy, negz, parx, pary, parz;
+};
+
+__device__ __forceinline__ SlabRay make_slab_ray(V3 o, V3 d)
+{
+    SlabRay s;
+    s.o = o;
+    s.parx = fabsf(d.x) < 1e-8f; s.pary = fabsf(d.y) < 1e-8f; s.parz = fabsf(d.z) < 1e-8f;
+    s.inv.x = 1.0f / d.x; s.inv.y = 1.0f / d.y; s.inv.z = 1.0f / d.z;
+    s.negx = s.inv.x < 0.0f; s.negy = s.inv.y < 0.0f; s.negz = s.inv.z < 0.0f;
+    return s;
+}
+
+// One axis of IntersectAABB. For a parallel axis the interval is left alone and
+// only containment is checked, exactly as the shader does.
+__device__ __forceinline__ void slab_axis(float o, float inv, bool neg, bool par, float mn, float mx,
+                                          float& tEnter, float& tExit, bool& ok)
+{
+    float t0 = (mn - o) * inv;
+    float t1 = (mx - o) * inv;
+    float lo = neg ? t1 : t0;
+    float hi = neg ? t0 : t1;
+    bool inside = !(o < mn || o > mx);
+    lo = par ? -INFINITY : lo;
+    hi = par ? INFINITY : hi;
+    ok = ok && (!par || inside);
+    tEnter = gmax(tEnter, lo);
+    tExit = gmin(tExit, hi);
+}
+
+// IntersectAABB split in two: the part that does not depend on the current
+// closest hit (returned: ok, entry distance E with tMin folded in, exit T1), and
+// the part that does (C > E), which the caller applies at the moment the
+// reference would run the test. The shader's per-axis early-outs
+// `if (t.max <= t.min) return false` are equivalent to the single final test
+// min(C,T1) > E because t.min only grows and t.max only shrinks.
+__device__ __forceinline__ bool slab_box(const SlabRay& r, V3 mn, V3 mx, float tMin, float& E)
+{
+    float e = tMin, x = INFINITY;
+    bool ok = true;
+    slab_axis(r.o.x, r.inv.x, r.negx, r.parx, mn.x, mx.x, e, x, ok);
+    slab_axis(r.o.y, r.inv.y, r.negy, r.pary, mn.y, mx.y, e, x, ok);
+    slab_axis(r.o.z, r.inv.z, r.negz, r.parz, mn.z, mx.z, e, x, ok);
+    E = e;
+    return ok && (x > e);
+}
+
+// raytrace.comp:345-355
+__device__ __forceinline__ float distance_to_aabb(V3 p, V3 mn, V3 mx)
+{
+    float sq = 0.0f;
+    if (p.x < mn.x) sq += (mn.x - p.x) * (mn.x - p.x);
+    if (p.x > mx.x) sq += (p.x - mx.x) * (p.x - mx.x);
+    if (p.y < mn.y) sq += (mn.y - p.y) * (mn.y - p.y);
+    if (p.y > mx.y) sq += (p.y - mx.y) * (p.y - mx.y);
+    if (p.z < mn.z) sq += (mn.z - p.z) * (mn.z - p.z);
+    if (p.z > mx.z) sq += (p.z - mx.z) * (p.z - mx.z);
+    return sqrtf(sq);
+}
+
+// rows 0..2 of a 3x4 matrix times (v,w), paired as (c0*x + c1*y) + (c2*z + c3*w)
+__device__ __forceinline__ V3 xform(const float* m, V3 v, float w)
+{
+    return mk((m[0] * v.x + m[1] * v.y) + (m[2] * v.z + m[3] * w),
+              (m[4] * v.x + m[5] * v.y) + (m[6] * v.z + m[7] * w),
+              (m[8] * v.x + m[9] * v.y) + (m[10] * v.z + m[11] * w));
+}
+
+struct Counters { int rays, nodeTests, triTests; };
+
+// What a GetHit call keeps while it walks: enough to rebuild the RayHit.
+struct Best {
+    float closest;   // closestSoFar (world t)
+    float tLocal;    // hitT of the winning triangle in object space
+    float u, v;
+    int   object;    // -1: nothing hit
+    int   tri;       // original triangle index
+};
+
+struct HitRec { V3 point, normal; int matIndex; float t; bool frontFace; bool hit; };
+
+#define RT_NONE 0x7fffffff
+
+// GetHit, raytrace.comp:448-610. dirN must already be normalize(r_in.direction).
+template <bool COUNT, bool ANYHIT>
+__device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org, V3 dirN, float tMin, float tMax,
+                                      Best& best, Counters& cnt, uint2* stack)
+{
+    best.closest = tMax;
+    best.object = -1;
+    best.tri = 0; best.u = 0.0f; best.v = 0.0f; best.tLocal = 0.0f;
+    if (COUNT) cnt.rays++;
+
+    const SlabRay wr = make_slab_ray(org, dirN);
+
+    for (int i = 0; i < parentCount; ++i) {
+        const DevObject* ob = S.objects + i;   // wave-uniform address
+        if (COUNT) cnt.nodeTests++;
+        V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+        float E;
+        bool ok = slab_box(wr, bmn, bmx, tMin, E) && (best.closest > E);
+        if (ok) ok = !(distance_to_aabb(org, bmn, bmx) > best.closest);
+        int cur = ob->root;
+        if (!ok || cur == RT_REF_EMPTY || cur == RT_REF_ABSENT) continue;
+
+        V3 lo = xform(ob->inv, org, 1.0f);
+        V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
+        const SlabRay lr = make_slab_ray(lo, ld);
+        int sp = 0;
+
+        for (;;) {
+            if (cur >= 0) {
+                const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+                float4 a = np[0], b = np[1], c = np[2];
+                int2 refs = *reinterpret_cast<const int2*>(np + 3);
+                float EF, ES;
+                bool okF = slab_box(lr, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
+                bool okS = slab_box(lr, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
+                bool presF = refs.x != RT_REF_ABSENT, presS = refs.y != RT_REF_ABSENT;
+                if (COUNT) cnt.nodeTests += (presF ? 1 : 0) + (presS ? 1 : 0);
+                bool goF = presF && okF && (best.closest > EF) && refs.x != RT_REF_EMPTY;
+                bool canS = presS && okS && refs.y != RT_REF_EMPTY;
+                if (goF) {
+                    if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(ES)); ++sp; }
+                    cur = refs.x;
+                    continue;
+                }
+                if (canS && (best.closest > ES)) { cur = refs.y; continue; }
+            } else {
+                int k = ~cur;
+                for (;;) {
+                    const float4* tp = reinterpret_cast<const float4*>(S.tris + k);
+                    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    if (COUNT) cnt.triTests++;
+                    // IntersectTriangle, raytrace.comp:278-328
+                    V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
+                    V3 h = cross3(ld, e2);
+                    float det = dot3(e1, h);
+                    const float eps = 1e-5f;
+                    if (!(fabsf(det) < eps)) {
+                        float invDet = 1.0f / det;
+                        V3 s = lo - v0;
+                        float u = invDet * dot3(s, h);
+                        V3 sc = cross3(s, e1);
+                        float v = invDet * dot3(ld, sc);
+                        bool miss = (u < -eps || u > 1.0f + eps) || (v < -eps || u + v > 1.0f + eps);
+                        float hitT = invDet * dot3(e2, sc);
+                        if (!miss && (hitT >= tMin && hitT <= best.closest) && hitT > eps) {
+                            // raytrace.comp:559-572
+                            V3 p = lo + ld * hitT;
+                            V3 wp = xform(ob->fwd, p, 1.0f);
+                            float worldT = dot3(wp - org, dirN);
+                            if (worldT > tMin && worldT < best.closest) {
+                                best.closest = worldT;
+                                best.tLocal = hitT;
+                                best.u = u; best.v = v;
+                                best.object = i;
+                                best.tri = __float_as_int(t1.w);
+                                if (ANYHIT) return true;
+                            }
+                        }
+                    }
+                    if (__float_as_int(t0.w) <= 1) break;
+                    ++k;
+                }
+            }
+            // pop: discard entries whose box no longer reaches inside the closest hit
+            cur = RT_NONE;
+            while (sp > 0) {
+                --sp;
+                uint2 e = stack[sp * 64];
+                if (best.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+            }
+            if (cur == RT_NONE) break;
+        }
+    }
+    return best.object >= 0;
+}
+
+// Rebuild the RayHit of the winning triangle (raytrace.comp:311-320 + 559-571).
+__device__ __forceinline__ void finish_hit(const DevScene& S, V3 org, V3 dirN, const Best& best, HitRec& rec)
+{
+    rec.hit = best.object >= 0;
+    rec.t = best.closest;
+    if (!rec.hit) return;
+    const DevObject* ob = S.objects + best.object;
+    V3 lo = xform(ob->inv, org, 1.0f);
+    V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
+    V3 p = lo + ld * best.tLocal;
+    rec.point = xform(ob->fwd, p, 1.0f);
+    const float4* np = reinterpret_cast<const float4*>(S.nrms + best.tri);
+    float4 a = np[0], b = np[1], c = np[2];
+    float w = 1.0f - best.u - best.v;
+    V3 interp = normalize3((mk(a.x, a.y, a.z) * w + mk(b.x, b.y, b.z) * best.u) + mk(c.x, c.y, c.z) * best.v);
+    bool frontLocal = dot3(ld, interp) < 0.0f;
+    V3 nl = frontLocal ? interp : -interp;
+    // normalMatrix = mat3(transpose(inverseTransform)); row r of the product is
+    // column r of inverseTransform dotted with the normal
+    const float* m = ob->inv;
+    V3 wn = mk(m[0] * nl.x + m[4] * nl.y + m[8] * nl.z,
+               m[1] * nl.x + m[5] * nl.y + m[9] * nl.z,
+               m[2] * nl.x + m[6] * nl.y + m[10] * nl.z);
+    rec.normal = normalize3(wn);
+    rec.matIndex = ob->materialIndex;
+    rec.frontFace = dot3(dirN, rec.normal) < 0.0f;
+}
+
+// ---- shading ------------------------------------------------------------------
+
+// raytrace.comp:363-369
+__device__ __forceinline__ float reflectance(float cosine, float refIdx)
+{
+    float r0 = (1.0f - refIdx) / (1.0f + refIdx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * gpow(1.0f - cosine, 5.0f);
+}
+__device__ __forceinline__ V3 reflect3(V3 I, V3 N) { return I - N * (2.0f * dot3(N, I)); }
+__device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta)
+{
+    float d = dot3(N, I);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f) return mk(0.0f, 0.0f, 0.0f);
+    return I * eta - N * (eta * d + sqrtf(k));
+}
+
+// raytrace.comp:623-668
+__device__ __forceinline__ V3 environment_colour(const rt_push_constants& pc, V3 rayDir)
+{
+    V3 unitDir = normalize3(rayDir);
+    V3 sunDir = normalize3(ld3(pc.sunDirection));
+    float sunDotUp = dot3(-sunDir, mk(0.0f, 1.0f, 0.0f));
+    const V3 dayZenith = mk(0.5f, 0.7f, 1.0f), dayHorizon = mk(1.0f, 1.0f, 1.0f), sunrise = mk(1.0f, 0.4f, 0.2f);
+    const V3 night = mk(0.0f, 0.0f, 0.0f);
+    float viewT = gclamp(0.5f * (unitDir.y + 1.0f), 0.0f, 1.0f);
+    V3 baseSky;
+    if (sunDotUp > 0.1f) {
+        baseSky = gmix3(dayHorizon, dayZenith, viewT);
+    } else if (sunDotUp > -0.1f) {
+        float blend = (sunDotUp + 0.1f) / 0.2f;
+        V3 daySky = gmix3(dayHorizon, dayZenith, viewT);
+        V3 sunSky = gmix3(sunrise, sunrise * 0.5f, viewT);
+        baseSky = gmix3(sunSky, daySky, blend);
+    } else {
+        baseSky = gmix3(night, night, viewT);
+    }
+    float cosTheta = gclamp(dot3(unitDir, -sunDir), 0.0f, 1.0f);
+    const float halfDegree = 0.5f * 0.017453292519943295f;
+    float sunDisk = expf(-gpow(acosf(cosTheta) / halfDegree, 2.0f));
+    V3 sunGlow = (ld3(pc.sunColour) * pc.sunIntensity) * sunDisk;
+    return baseSky + sunGlow;
+}
+
+// raytrace.comp:676-690 with SampleSquare (Random.glsl:43-49) and
+// DefocusDiskSample / RandomInUnitDisk (raytrace.comp:670-674, Random.glsl:51-60).
+// The seed arrives by value: the caller's state is not advanced.
+__device__ __forceinline__ Ray get_ray(const rt_push_constants& pc, int px, int py, uint32_t seed)
+{
+    seed += 1u;
+    float sx = rng_range(0.0f, 1.0f, seed);
+    float sy = rng_range(0.0f, 1.0f, seed);
+    float ox = sx - 0.5f, oy = sy - 0.5f;
+    V3 ps = (ld3(pc.pixel00Location) + ld3(pc.pixelDeltaU) * ((float)px + ox)) + ld3(pc.pixelDeltaV) * ((float)py + oy);
+    V3 origin;
+    if (pc.defocusAngle <= 0.0f) {
+        origin = ld3(pc.cameraPosition);
+    } else {
+        uint32_t s2 = seed + 1u;
+        V3 p;
+        for (;;) {
+            float dx = rng_range(-1.0f, 1.0f, s2);
+            float dy = rng_range(-1.0f, 1.0f, s2);
+            p = mk(dx, dy, 0.0f);
+            if (sqrtf(length3(p)) < 1.0f) break;
+        }
+        origin = (ld3(pc.cameraPosition) + ld3(pc.defocusDiskU) * p.x) + ld3(pc.defocusDiskV) * p.y;
+    }
+    Ray r;
+    r.o = origin;
+    r.d = normalize3(ps - origin);
+    return r;
+}
+
+__device__ __forceinline__ DevMaterial load_material(const DevScene& S, int idx)
+{
+    const float4* mp = reinterpret_cast<const float4*>(S.materials + idx);
+    float4 a = mp[0], b = mp[1], c = mp[2];
+    DevMaterial m;
+    m.colour[0] = a.x; m.colour[1] = a.y; m.colour[2] = a.z; m.smoothness = a.w;
+    m.fuzziness = b.x; m.emission = b.y; m.refractionIndex = b.z; m.pad1 = b.w;
+    m.absorbtion[0] = c.x; m.absorbtion[1] = c.y; m.absorbtion[2] = c.z; m.pad3 = c.w;
+    return m;
+}
+
+// MaterialScatter + DielectricScatter, raytrace.comp:371-423. `seed` by value.
+__device__ __forceinline__ void material_scatter(const DevMaterial& m, V3 rayDir, const HitRec& rec, uint32_t seed,
+                                                 V3& attenuation, Ray& scattered)
+{
+    float scatterOrReflect = rng_range(0.0f, 1.0f, seed);
+    if (m.refractionIndex > 0.0f) {
+        float refIdx = m.refractionIndex;
+        V3 ab = ld3(m.absorbtion);
+        V3 e = mk(expf(-ab.x * rec.t), expf(-ab.y * rec.t), expf(-ab.z * rec.t));
+        attenuation = ld3(m.colour) * e;
+        float etai = rec.frontFace ? (1.0f / refIdx) : refIdx;
+        V3 unit = normalize3(rayDir);
+        float cosTheta = gmin(dot3(-unit, rec.normal), 1.0f);
+        float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        bool cannotRefract = etai * sinTheta > 1.0f;
+        V3 dir;
+        if (cannotRefract || reflectance(cosTheta, refIdx) > rng_range(0.0f, 1.0f, seed))
+            dir = reflect3(unit, rec.normal);
+        else
+            dir = refract3(unit, rec.normal, etai);
+        scattered.o = rec.point;
+        scattered.d = normalize3(dir);
+        return;
+    }
+    const float EPSILON = 1e-4f;
+    if (scatterOrReflect < m.smoothness) {
+        V3 reflected = reflect3(normalize3(rayDir), rec.normal);
+        reflected = reflected + random_on_hemisphere(rec.normal, seed) * m.fuzziness;
+        scattered.o = rec.point + reflected * EPSILON;
+        scattered.d = normalize3(reflected);
+        attenuation = ld3(m.colour);
+    } else {
+        V3 sd = rec.normal + random_unit_vector(seed);
+        const float s = 1e-8f;
+        if (fabsf(sd.x) < s && fabsf(sd.y) < s && fabsf(sd.z) < s) sd = rec.normal;
+        scattered.o = rec.point + sd * EPSILON;
+        scattered.d = normalize3(sd);
+        attenuation = ld3(m.colour);
+    }
+}
+
+// RayColour, raytrace.comp:692-769. The shader passes `seed` on by value at
+// every bounce, so every bounce of one sample draws the same numbers.
+template <bool COUNT>
+__device__ __forceinline__ V3 ray_colour(const DevScene& S, const rt_push_constants& pc, Ray ray, uint32_t seed,
+                                         Counters& cnt, uint2* stack)
+{
+    V3 result = mk(0.0f, 0.0f, 0.0f);
+    V3 throughput = mk(1.0f, 1.0f, 1.0f);
+    const int bounces = pc.maxBounces + 1;
+    for (int bounce = 0; bounce < bounces; ++bounce) {
+        V3 dirN = normalize3(ray.d);
+        Best best;
+        trace<COUNT, false>(S, pc.parentBVHCount, ray.o, dirN, 0.001f, 1e20f, best, cnt, stack);
+        HitRec rec;
+        finish_hit(S, ray.o, dirN, best, rec);
+        if (!rec.hit) {
+            result = result + throughput * environment_colour(pc, ray.d);
+            break;
+        }
+        if (!rec.frontFace) break;
+
+        DevMaterial m = load_material(S, rec.matIndex);
+        V3 emitted = ld3(m.colour) * m.emission;
+        result = result + throughput * emitted;
+        if (m.emission > 0.0f) break;
+
+        V3 negSun = -ld3(pc.sunDirection);
+        float nDotL = gmax(dot3(rec.normal, negSun), 0.0f);
+        if (nDotL > 0.0f) {
+            V3 so = rec.point + rec.normal * 0.01f;
+            Best sb;
+            bool blocked = trace<COUNT, !COUNT>(S, pc.parentBVHCount, so, normalize3(negSun), 0.001f, 1e20f, sb, cnt, stack);
+            if (!blocked) {
+                V3 sun = ld3(pc.sunColour) * pc.sunIntensity;
+                const float INV_PI = 0.31830988618f;
+                V3 direct = sun * (nDotL * INV_PI);
+                if (m.refractionIndex == 0.0f) {
+                    result = result + (throughput * ld3(m.colour)) * direct;
+                } else {
+                    float fresnel = reflectance(nDotL, m.refractionIndex);
+                    result = result + (throughput * fresnel) * direct;
+                }
+            }
+        }
+        V3 attenuation;
+        Ray scattered;
+        material_scatter(m, ray.d, rec, seed, attenuation, scattered);
+        throughput = throughput * attenuation;
+        ray = scattered;
+    }
+    return result;
+}
+
+__device__ __forceinline__ float linear_to_gamma(float c) { return c > 0.0f ? sqrtf(c) : 0.0f; }
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+} // namespace
+
+// main(), raytrace.comp:857-875. One 64-lane block renders one 8x8 pixel tile.
+// statsOnly != 0: write no image, only add the work counters to *counters.
+template <bool COUNT>
+__global__ __launch_bounds__(64) void RT_SYM(rt_megakernel)(DevScene S, rt_push_constants pc, DevLaunch L,
+                                                            float4* __restrict__ accum, float4* __restrict__ out,
+                                                            DevCounters* counters, int statsOnly)
+{
+    extern __shared__ uint2 stackMem[];
+    const int lane = threadIdx.x;
+    uint2* stack = stackMem + lane;
+
+    const int wavesX = L.tileSize >> 3;
+    const int wavesPerTile = wavesX * wavesX;
+    const int ownedTile = blockIdx.x / wavesPerTile;
+    const int sub = blockIdx.x - ownedTile * wavesPerTile;
+    const int tile = L.tileRank + ownedTile * L.tileWorld;
+    const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
+    const int sy = sub / wavesX, sx = sub - sy * wavesX;
+    const int x = tx * L.tileSize + sx * 8 + (lane & 7);
+    const int y = ty * L.tileSize + sy * 8 + (lane >> 3);
+    const bool inside = x < L.width && y < L.height;
+
+    Counters cnt;
+    cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0;
+    int samples = 0;
+
+    if (inside) {
+        const size_t idx = (size_t)y * (size_t)L.width + (size_t)x;
+        const int mode = pc.renderMode;
+        if (mode == 0 || mode == 3 || mode == 4) {
+            // Pathtrace, raytrace.comp:771-817
+            float raysPerPixelRatio = 1.0f / (float)pc.raysPerPixel;
+            float accumulationMultiplier = pc.accumulateFrames == 1 ? 1.0f / (float)(pc.frame + 1) : 1.0f;
+            V3 nc = mk(0.0f, 0.0f, 0.0f);
+            for (int i = 0; i < pc.raysPerPixel; ++i) {
+                uint32_t seed = seed_from_coords((uint32_t)x, (uint32_t)y, (uint32_t)pc.frame, (uint32_t)i);
+                Ray ray = get_ray(pc, x, y, seed);
+                nc = nc + ray_colour<COUNT>(S, pc, ray, seed, cnt, stack);
+                samples++;
+            }
+            if (!statsOnly) {
+                if (mode == 0) {
+                    float4 acc = accum[idx];
+                    nc = nc * raysPerPixelRatio;
+                    acc.x += nc.x; acc.y += nc.y; acc.z += nc.z;
+                    accum[idx] = acc;
+                    float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(nc.x, nc.y, nc.z, 1.0f);
+                    avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
+                    out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
+                } else {
+                    int threshold = mode == 3 ? pc.triangleTestThreshold : pc.bvhNodeTestThreshold;
+                    int target = mode == 3 ? cnt.triTests : cnt.nodeTests;
+                    int grey = (int)((float)target / (float)threshold * 255.0f);
+                    grey = grey < 0 ? 0 : (grey > 255 ? 255 : grey);
+                    float g = (float)grey / 255.0f;
+                    float4 c = make_float4(g, g, g, 1.0f);
+                    if (cnt.triTests > threshold) c = make_float4(1.0f, 0.0f, 0.0f, 1.0f);
+                    out[idx] = c;
+                }
+            }
+        } else if (mode == 1) {
+            // RenderBoundingBoxes, raytrace.comp:819-835
+            Ray ray = get_ray(pc, x, y, 123u);
+            SlabRay wr = make_slab_ray(ray.o, ray.d);
+            float red = 0.0f;
+            for (int i = 0; i < pc.parentBVHCount; ++i) {
+                const DevObject* ob = S.objects + i;
+                float E;
+                if (slab_box(wr, ld3(ob->bmin), ld3(ob->bmax), 0.001f, E) && (1e20f > E)) { red = 1.0f; break; }
+            }
+            if (!statsOnly) out[idx] = make_float4(red, 0.0f, 0.0f, 1.0f);
+        } else if (mode == 2) {
+            // RenderDepth, raytrace.comp:837-855
+            Ray ray = get_ray(pc, x, y, 123u);
+            V3 dirN = normalize3(ray.d);
+            Best best;
+            trace<COUNT, false>(S, pc.parentBVHCount, ray.o, dirN, 0.001f, 1e20f, best, cnt, stack);
+            HitRec rec;
+            finish_hit(S, ray.o, dirN, best, rec);
+            float d = 0.0f;
+            if (rec.hit) {
+                d = length3(rec.point - ld3(pc.cameraPosition));
+                d = gclamp(d / pc.depthDebugScale, 0.0f, 1.0f);
+            }
+            if (!statsOnly) out[idx] = make_float4(d, d, d, 1.0f);
+        }
+    }
+
+    if (COUNT && counters != nullptr) {
+        int r = wave_sum(cnt.rays), n = wave_sum(cnt.nodeTests), t = wave_sum(cnt.triTests), s = wave_sum(samples);
+        if (lane == 0) {
+            atomicAdd(&counters->rays, (unsigned long long)r);
+            atomicAdd(&counters->nodeTests, (unsigned long long)n);
+            atomicAdd(&counters->triTests, (unsigned long long)t);
+            atomicAdd(&counters->samples, (unsigned long long)s);
+        }
+    }
+}
+
+// draw = gamma(accum.rgb * 1/total_frames), draw.a = accum.a (raytrace.comp:794-801)
+__global__ __launch_bounds__(256) void RT_SYM(rt_resolve_kernel)(const float4* __restrict__ accum, float4* __restrict__ out,
+                                                                 size_t pixels, float multiplier)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < pixels; i += stride) {
+        float4 a = accum[i];
+        a.x *= multiplier; a.y *= multiplier; a.z *= multiplier;
+        out[i] = make_float4(linear_to_gamma(a.x), linear_to_gamma(a.y), linear_to_gamma(a.z), a.w);
+    }
+}
+
+// ---- launchers (called from rt_host.cpp) ---------------------------------------
+
+extern "C" hipError_t RT_SYM(rt_launch_megakernel)(const DevScene* S, const rt_push_constants* pc, const DevLaunch* L,
+                                                   void* accum, void* out, DevCounters* counters, int countBuild,
+                                                   int statsOnly, hipStream_t stream)
+{
+    const int wavesX = L->tileSize / 8;
+    const long long blocks = (long long)L->ownedTiles * wavesX * wavesX;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
+    dim3 grid((unsigned)blocks), block(64);
+    if (countBuild)
+        hipLaunchKernelGGL(RT_SYM(rt_megakernel)<true>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out,
+                           counters, statsOnly);
+    else
+        hipLaunchKernelGGL(RT_SYM(rt_megakernel)<false>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out,
+                           counters, statsOnly);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t RT_SYM(rt_launch_resolve)(const void* accum, void* out, size_t pixels, float multiplier, hipStream_t stream)
+{
+    if (pixels == 0) return hipSuccess;
+    size_t blocks = (pixels + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(RT_SYM(rt_resolve_kernel), dim3((unsigned)blocks), dim3(256), 0, stream, (const float4*)accum,
+                       (float4*)out, pixels, multiplier);
+    return hipGetLastError();
+}
