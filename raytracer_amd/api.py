@@ -110,6 +110,13 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RtError(-100, "%s is missing: build it with `make -C raytracer_amd/csrc` (there is no fallback path)" % LIB_PATH)
+    # PyTorch wheels bundle their own libamdhip64.so (same SONAME as the system one, but requested
+    # under a different file name). Two HIP runtimes in one process cannot both own the GPU, so
+    # let torch load its copy first: the loader then binds this library to that same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     P = C.POINTER

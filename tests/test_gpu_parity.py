@@ -1,0 +1,429 @@
+"""GPU parity tests: the HIP path (through the C ABI of librt_amd.so) against the CPU oracle on
+the same scene arrays, seeds and push constants.
+
+Bars, stated per test:
+  * strict flavour (no FMA contraction), scenes without transcendental shading (the default
+    scene): accumulation image, draw image and the integer counter images are BIT-EXACT;
+  * scenes that reach exp/pow/acos (glass, sky): >= 99.5 % of pixels within
+    |d| <= 1e-4 + 1e-4*|ref| per channel (device libm differs from glibc in the last bits, and
+    a last-bit difference can flip a discrete branch of a path), counters equal on >= 99.5 %;
+  * fast flavour (FMA contraction allowed): same 99.5 % bar at 1 spp, PSNR >= 45 dB on the
+    gamma image after 64 accumulated frames.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import scenes
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(O.ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def R():
+    import raytracer_amd
+    return raytracer_amd
+
+
+@pytest.fixture(scope="module")
+def rdr(R, default_scene_arrays):
+    r = R.Renderer(0)
+    r.upload_scene(default_scene_arrays)
+    yield r
+    r.close()
+
+
+def to_pc(R, opc):
+    return R.PushConstants.from_buffer_copy(O.pc_bytes(opc).tobytes())
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def within(a, ref, tol_abs=1e-4, tol_rel=1e-4):
+    with np.errstate(invalid="ignore"):
+        ok = np.abs(a - ref) <= tol_abs + tol_rel * np.abs(ref)
+    ok |= np.isnan(a) & np.isnan(ref)
+    return float(np.mean(np.all(ok, axis=-1)))
+
+
+def gpu_frames(R, r, opc, frames, W, H, clear=True):
+    r.resize(W, H) if (r.width, r.height) != (W, H) else None
+    if clear:
+        r.clear_accumulation()
+    for f in frames:
+        opc["frame"] = f
+        r.render_frame(to_pc(R, opc))
+    return r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW)
+
+
+def oracle_frames(arrays, opc, frames, W, H, counters=False):
+    acc = np.zeros((H, W, 4), np.float32)
+    res = None
+    for f in frames:
+        opc["frame"] = f
+        res = O.render(arrays, O.pc_bytes(opc), W, H, accum=acc, counters=counters)
+        acc = res["accum"]
+    return res
+
+
+def test_default_scene_bit_exact_vs_golden_and_oracle(R, rdr, default_scene_arrays):
+    g = np.load(os.path.join(GOLDEN, "default_128x72_f0f1.npz"))
+    W, H = 128, 72
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    acc, out = gpu_frames(R, rdr, opc, [0, 1], W, H)
+    assert np.array_equal(bits(acc), bits(g["accum"]))
+    assert np.array_equal(bits(out), bits(g["out"]))
+    o = oracle_frames(default_scene_arrays, opc, [0, 1], W, H)
+    assert np.array_equal(bits(acc), bits(o["accum"])) and np.array_equal(bits(out), bits(o["out"]))
+
+
+def test_config1_1280x720_full_frame_bit_exact(R, rdr, default_scene_arrays):
+    """BASELINE config 1: default scene, 1280x720, 1 spp, shipped bounce count, frame 0."""
+    W, H = 1280, 720
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    acc, out = gpu_frames(R, rdr, opc, [0], W, H)
+    o = oracle_frames(default_scene_arrays, opc, [0], W, H, counters=True)
+    assert np.array_equal(bits(acc), bits(o["accum"]))
+    assert np.array_equal(bits(out), bits(o["out"]))
+    g = np.load(os.path.join(GOLDEN, "default_1280x720_crop.npz"))
+    x0, y0, x1, y1 = [int(v) for v in g["window"]]
+    assert np.array_equal(bits(acc[y0:y1, x0:x1]), bits(g["accum"]))
+    # work counters summed over the frame, from the counting build of the kernel
+    opc["frame"] = 0
+    st = rdr.frame_stats(to_pc(R, opc))
+    assert (st.rays, st.bvhNodeTests, st.triangleTests) == (int(o["rays"].sum()), int(o["node"].sum()), int(o["tri"].sum()))
+    assert st.samples == W * H
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_debug_modes_bit_exact(R, rdr, default_scene_arrays, mode):
+    W, H = 160, 90
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    opc = scenes.make_pc(default_scene_arrays, W, H, renderMode=mode)
+    rdr.resize(W, H)
+    rdr.render_frame(to_pc(R, opc))
+    got = rdr.read_image(R.RT_IMAGE_DRAW)
+    want = O.render(default_scene_arrays, O.pc_bytes(opc), W, H)["out"]
+    assert np.array_equal(bits(got), bits(want))
+    if mode == 2:
+        g = np.load(os.path.join(GOLDEN, "default_128x72_depth.npz"))
+        opc2 = scenes.make_pc(default_scene_arrays, 128, 72, renderMode=2)
+        rdr.resize(128, 72)
+        rdr.render_frame(to_pc(R, opc2))
+        assert np.array_equal(bits(rdr.read_image(R.RT_IMAGE_DRAW)), bits(g["out"]))
+
+
+def test_counter_images_equal(R, rdr, default_scene_arrays):
+    """Per-pixel triangleTests / bvhNodeTests (reference traversal order) through modes 3/4 with
+    thresholds that keep the grey ramp fine-grained (grey = int(tests / threshold * 255))."""
+    W, H = 160, 90
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    rdr.resize(W, H)
+    o = O.render(default_scene_arrays, O.pc_bytes(scenes.make_pc(default_scene_arrays, W, H)), W, H, counters=True)
+    assert o["tri"].max() > 100 and o["node"].max() > 100
+    for mode in (3, 4):
+        for thr in (255, 1000, 4000):
+            opc = scenes.make_pc(default_scene_arrays, W, H, renderMode=mode, triangleTestThreshold=thr, bvhNodeTestThreshold=thr)
+            rdr.render_frame(to_pc(R, opc))
+            got = rdr.read_image(R.RT_IMAGE_DRAW)
+            want = O.render(default_scene_arrays, O.pc_bytes(opc), W, H)["out"]
+            assert np.array_equal(bits(got), bits(want))
+            assert len(np.unique(want[..., 1])) > 8      # not a trivially flat image
+
+
+@pytest.mark.parametrize("fields", [
+    dict(raysPerPixel=3), dict(maxBounces=0), dict(maxBounces=7), dict(accumulateFrames=0),
+    dict(raysPerPixel=2, maxBounces=1, accumulateFrames=0),
+    dict(sunDirection=(-0.3, -0.9, 0.2), sunIntensity=2.0)])
+def test_settings_surface_bit_exact(R, rdr, default_scene_arrays, fields):
+    W, H = 96, 54
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    opc = scenes.make_pc(default_scene_arrays, W, H, **fields)
+    acc, out = gpu_frames(R, rdr, opc, [0, 1, 2], W, H)
+    o = oracle_frames(default_scene_arrays, opc, [0, 1, 2], W, H)
+    assert np.array_equal(bits(acc), bits(o["accum"])) and np.array_equal(bits(out), bits(o["out"]))
+
+
+@pytest.mark.parametrize("W,H", [(37, 23), (8, 8), (1, 1), (65, 9), (200, 3)])
+def test_ragged_sizes_bit_exact(R, rdr, default_scene_arrays, W, H):
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    acc, out = gpu_frames(R, rdr, opc, [5], W, H)
+    o = oracle_frames(default_scene_arrays, opc, [5], W, H)
+    assert np.array_equal(bits(acc), bits(o["accum"])) and np.array_equal(bits(out), bits(o["out"]))
+
+
+def test_camera_and_defocus_bit_exact(R, rdr, default_scene_arrays):
+    W, H = 120, 80
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    opc = scenes.make_pc(default_scene_arrays, W, H, cam_pos=(1.5, 3.0, 4.0), look=(-0.3, -0.25, -1.0), fov=55.0, focus=6.0, defocus=3.0)
+    acc, out = gpu_frames(R, rdr, opc, [0, 1], W, H)
+    o = oracle_frames(default_scene_arrays, opc, [0, 1], W, H)
+    assert np.array_equal(bits(acc), bits(o["accum"])) and np.array_equal(bits(out), bits(o["out"]))
+
+
+def test_fast_flavour_within_tolerance(R, rdr, default_scene_arrays):
+    W, H = 320, 180
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    rdr.set_option(R.RT_OPT_FAST_MATH, 1)
+    try:
+        acc, out = gpu_frames(R, rdr, opc, [0], W, H)
+    finally:
+        rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    o = oracle_frames(default_scene_arrays, opc, [0], W, H)
+    assert within(acc[..., :3], o["accum"][..., :3]) >= 0.995
+
+
+def test_converged_psnr(R, rdr, default_scene_arrays):
+    """64 accumulated frames at 256x144: strict is bit-exact, fast has PSNR >= 45 dB on the gamma image."""
+    W, H = 256, 144
+    frames = list(range(64))
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    o = oracle_frames(default_scene_arrays, opc, frames, W, H)
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    acc, out = gpu_frames(R, rdr, opc, frames, W, H)
+    assert np.array_equal(bits(acc), bits(o["accum"])) and np.array_equal(bits(out), bits(o["out"]))
+    rdr.set_option(R.RT_OPT_FAST_MATH, 1)
+    try:
+        acc, out = gpu_frames(R, rdr, opc, frames, W, H)
+    finally:
+        rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    a = np.clip(out[..., :3], 0, 1).astype(np.float64)
+    b = np.clip(o["out"][..., :3], 0, 1).astype(np.float64)
+    mse = np.mean((a - b) ** 2)
+    psnr = 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+    assert psnr >= 45.0, psnr
+
+
+def test_mixed_material_scene(R):
+    """Glass (exp/pow), mirror, fuzzy metal, emitter, open sky (acos/exp/pow), sub-unit and
+    non-uniform scales, a model without normals and one with a 287-triangle leaf."""
+    materials, objects = scenes.mixed_recipe()
+    arrays = scenes.build_oracle(materials, objects).bindings()
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(arrays)
+        W, H = 256, 144
+        opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 2.5, 8.0), look=(0.0, -0.15, -1.0), fov=60.0, maxBounces=5)
+        acc, out = gpu_frames(R, r, opc, [0, 1], W, H)
+        o = oracle_frames(arrays, opc, [0, 1], W, H, counters=True)
+        frac = within(acc[..., :3], o["accum"][..., :3])
+        assert frac >= 0.995, frac
+        # NaN pattern (Reflectance(pow of a negative base) on glass lit by the un-normalised sun) must agree too
+        assert np.mean(np.isnan(acc) == np.isnan(o["accum"])) >= 0.999
+        opc["frame"] = 1
+        st = r.frame_stats(to_pc(R, opc))
+        ref = (int(o["rays"].sum()), int(o["node"].sum()), int(o["tri"].sum()))
+        got = (st.rays, st.bvhNodeTests, st.triangleTests)
+        for a, b in zip(got, ref):
+            assert abs(a - b) <= 0.005 * b, (got, ref)
+        # depth view has no transcendental in it: bit-exact, including the objects scaled below 1
+        opc2 = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 2.5, 8.0), look=(0.0, -0.15, -1.0), fov=60.0, renderMode=2)
+        r.render_frame(to_pc(R, opc2))
+        want = O.render(arrays, O.pc_bytes(opc2), W, H)["out"]
+        assert np.array_equal(bits(r.read_image(R.RT_IMAGE_DRAW)), bits(want))
+    finally:
+        r.close()
+
+
+def test_empty_scene_is_all_sky(R):
+    arrays = [np.zeros(0, d) for d in O.BINDING_DTYPES]
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(arrays)
+        W, H = 64, 40
+        opc = scenes.make_pc(arrays, W, H)
+        acc, out = gpu_frames(R, r, opc, [0], W, H)
+        o = oracle_frames(arrays, opc, [0], W, H)
+        assert within(acc[..., :3], o["accum"][..., :3], 1e-5, 1e-5) == 1.0
+        assert acc[..., :3].min() > 0.4     # day sky everywhere
+    finally:
+        r.close()
+
+
+def test_tile_partition_is_bit_identical(R, rdr, default_scene_arrays):
+    """Tile split across N ranks: every rank renders only its tiles; the union equals the single-GPU image."""
+    W, H = 200, 120
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    full_acc, full_out = gpu_frames(R, rdr, opc, [0, 1], W, H)
+    world = 3
+    rdr.set_option(R.RT_OPT_TILE_SIZE, 32)
+    rdr.set_option(R.RT_OPT_TILE_WORLD, world)
+    try:
+        sum_acc = np.zeros_like(full_acc)
+        owner = np.zeros((H, W), np.int32)
+        for rank in range(world):
+            rdr.set_option(R.RT_OPT_TILE_RANK, rank)
+            rdr.resize(W, H)                       # fresh, zeroed draw + accumulation images
+            acc, out = gpu_frames(R, rdr, opc, [0, 1], W, H)
+            touched = np.any(bits(acc) != 0, axis=2) | np.any(bits(out) != 0, axis=2)
+            owner += touched
+            sum_acc += acc
+            ty, tx = np.mgrid[0:H, 0:W]
+            mine = ((ty // 32) * ((W + 31) // 32) + tx // 32) % world == rank
+            assert not np.any(touched & ~mine)
+            assert np.array_equal(bits(acc[mine]), bits(full_acc[mine]))
+            assert np.array_equal(bits(out[mine]), bits(full_out[mine]))
+        assert np.array_equal(bits(sum_acc), bits(full_acc))
+    finally:
+        rdr.set_option(R.RT_OPT_TILE_RANK, 0)
+        rdr.set_option(R.RT_OPT_TILE_WORLD, 1)
+        rdr.set_option(R.RT_OPT_TILE_SIZE, 64)
+
+
+def test_sample_split_merge_and_resolve(R, rdr, default_scene_arrays):
+    """Sample split: rank g renders frames g, g+N, ...; the summed accumulation images, resolved with
+    1/total, match the sequential render up to f32 re-association of the per-pixel sum."""
+    W, H = 160, 90
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    total, world = 8, 2
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    seq_acc, seq_out = gpu_frames(R, rdr, opc, list(range(total)), W, H)
+    parts = []
+    for rank in range(world):
+        rdr.clear_accumulation()
+        rdr.render_frames(to_pc(R, opc), rank, world, total // world)
+        parts.append(rdr.read_image(R.RT_IMAGE_ACCUM))
+    merged = parts[0] + parts[1]
+    rdr.write_accum(merged)
+    rdr.resolve(total)
+    out = rdr.read_image(R.RT_IMAGE_DRAW)
+    assert np.array_equal(bits(rdr.read_image(R.RT_IMAGE_ACCUM)), bits(merged))
+    np.testing.assert_allclose(merged[..., :3], seq_acc[..., :3], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out[..., :3], seq_out[..., :3], rtol=1e-5, atol=1e-6)
+    want = np.sqrt(np.maximum(merged[..., :3] * np.float32(1.0 / total), 0), dtype=np.float32)
+    assert np.array_equal(bits(out[..., :3]), bits(want))
+
+
+def test_full_size_properties(R, rdr, default_scene_arrays):
+    """BASELINE config 2 size (2560x1369), too big for the oracle in a test: size-independent properties."""
+    W, H = 2560, 1369
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    opc = scenes.make_pc(default_scene_arrays, W, H, accumulateFrames=0)
+    rdr.resize(W, H)
+    singles = []
+    for f in range(3):
+        rdr.clear_accumulation()
+        opc["frame"] = f
+        rdr.render_frame(to_pc(R, opc))
+        singles.append(rdr.read_image(R.RT_IMAGE_ACCUM))
+    # determinism: the same frame twice gives the same bits
+    rdr.clear_accumulation()
+    opc["frame"] = 2
+    rdr.render_frame(to_pc(R, opc))
+    assert np.array_equal(bits(rdr.read_image(R.RT_IMAGE_ACCUM)), bits(singles[2]))
+    # progressive accumulation is the in-order f32 sum of the single frames
+    opc2 = scenes.make_pc(default_scene_arrays, W, H)
+    acc, out = gpu_frames(R, rdr, opc2, [0, 1, 2], W, H)
+    want = (singles[0] + singles[1]) + singles[2]
+    assert np.array_equal(bits(acc), bits(want))
+    assert np.array_equal(bits(out[..., :3]), bits(np.sqrt(np.maximum(want[..., :3] * np.float32(1.0 / 3.0), 0), dtype=np.float32)))
+    assert np.all(out[..., 3] == 0)
+    # a window of the big frame against the oracle (pixels do not depend on their neighbours)
+    o = O.render(default_scene_arrays, O.pc_bytes(scenes.make_pc(default_scene_arrays, W, H)), W, H, window=(1200, 600, 1328, 664))
+    assert np.array_equal(bits(singles[0][600:664, 1200:1328]), bits(o["accum"][600:664, 1200:1328]))
+    # ray budget: 1..8 GetHit calls per sample
+    opc2["frame"] = 0
+    st = rdr.frame_stats(to_pc(R, opc2))
+    assert st.samples == W * H and W * H <= st.rays <= 8 * W * H and st.bvhNodeTests >= 8 * st.rays
+
+
+def test_write_accum_resume(R, rdr, default_scene_arrays):
+    W, H = 64, 48
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    acc3, out3 = gpu_frames(R, rdr, opc, [0, 1, 2], W, H)
+    acc2, _ = gpu_frames(R, rdr, opc, [0, 1], W, H)
+    rdr.clear_accumulation()
+    rdr.write_accum(acc2)
+    a, o = gpu_frames(R, rdr, opc, [2], W, H, clear=False)
+    assert np.array_equal(bits(a), bits(acc3)) and np.array_equal(bits(o), bits(out3))
+
+
+def test_bound_images(R, rdr, default_scene_arrays):
+    """Rendering into caller-owned device memory (torch tensors) on the caller's stream."""
+    import torch
+    W, H = 96, 64
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    want_acc, want_out = gpu_frames(R, rdr, opc, [0, 1], W, H)
+    draw = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    rdr.bind_images(draw.data_ptr(), accum.data_ptr(), W, H)
+    rdr.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for f in (0, 1):
+            opc["frame"] = f
+            rdr.render_frame(to_pc(R, opc))
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(accum.cpu().numpy()), bits(want_acc))
+        assert np.array_equal(bits(draw.cpu().numpy()), bits(want_out))
+    finally:
+        rdr.set_stream(None)
+        rdr.bind_images(None, None, 0, 0)
+
+
+def test_error_paths(R, default_scene_arrays):
+    r = R.Renderer(0)
+    try:
+        pc = R.default_push_constants()
+        with pytest.raises(R.RtError) as e:
+            r.render_frame(pc)
+        assert e.value.code == -4                      # no scene
+        r.upload_scene(default_scene_arrays)
+        with pytest.raises(R.RtError) as e:
+            r.render_frame(pc)
+        assert e.value.code == -5                      # no images
+        r.resize(16, 16)
+        pc.parentBVHCount = 9
+        with pytest.raises(R.RtError) as e:
+            r.render_frame(pc)
+        assert "parentBVHCount" in str(e.value)
+        buf = np.zeros(10, np.float32)
+        assert r.lib.rt_read_image(r.h, 0, buf.ctypes.data, buf.nbytes) == -1
+        with pytest.raises(R.RtError):
+            r.resize(0, 5)
+        with pytest.raises(R.RtError):
+            r.set_option(R.RT_OPT_PIPELINE, 7)
+        # invalid scenes are rejected at upload instead of faulting the GPU
+        bad = [a.copy() for a in default_scene_arrays]
+        bad[14][5] = 10 ** 6                           # child index out of range
+        with pytest.raises(R.RtError) as e:
+            r.upload_scene(bad)
+        assert e.value.code == -6
+        bad = [a.copy() for a in default_scene_arrays]
+        l0 = int(bad[14][98])                          # make the dragon's first inner node its own grandchild
+        bad[14][l0] = 98
+        with pytest.raises(R.RtError) as e:
+            r.upload_scene(bad)
+        assert e.value.code == -6 and ("cycle" in str(e.value) or "deeper" in str(e.value))
+        bad = [a.copy() for a in default_scene_arrays]
+        bad[16][200] = 10 ** 7                         # leaf triangle range outside the arrays
+        with pytest.raises(R.RtError):
+            r.upload_scene(bad)
+        bad = [a.copy() for a in default_scene_arrays]
+        bad[1].view(np.int32).reshape(8, 20)[3, 2] = -1   # GetMaterialIndex's "not found"
+        with pytest.raises(R.RtError) as e:
+            r.upload_scene(bad)
+        assert "material" in str(e.value)
+        bad = [a.copy() for a in default_scene_arrays]
+        bad[4] = bad[4][:-4]
+        with pytest.raises(R.RtError):
+            r.upload_scene(bad)
+        # the context is still usable afterwards
+        r.upload_scene(default_scene_arrays)
+        pc = to_pc(R, scenes.make_pc(default_scene_arrays, 16, 16))
+        r.render_frame(pc)
+        r.sync()
+    finally:
+        r.close()
