@@ -48,8 +48,11 @@ enum {
      * compared value-for-value with the CPU oracle); 1 = same algorithm with FMA
      * contraction allowed. Default 0. */
     RT_OPT_FAST_MATH   = 1,
-    /* 0 = megakernel (one lane walks a whole pixel); 1 = wavefront pipeline
-     * (generate / extend / shade kernels over compacted ray queues). Default 0. */
+    /* Kernel that renders modes 0/3/4. 0 (default) = lock-step megakernel: one lane per pixel,
+     * the 64 lanes of a wave walk the same GetHit call together. 1 = wave-scheduled persistent
+     * megakernel: every lane runs its own state machine, the wave votes which kind of round
+     * (object loop / BVH walk / shading) to run next, finished lanes pull new pixels from a
+     * global counter. Same arithmetic, same results. */
     RT_OPT_PIPELINE    = 2,
     /* Tile partition for multi-GPU tile split: this context renders only the
      * tiles t with t % RT_OPT_TILE_WORLD == RT_OPT_TILE_RANK (tiles are
@@ -57,7 +60,9 @@ enum {
      * other tiles are left untouched. Defaults: rank 0, world 1, size 64. */
     RT_OPT_TILE_RANK   = 3,
     RT_OPT_TILE_WORLD  = 4,
-    RT_OPT_TILE_SIZE   = 5
+    RT_OPT_TILE_SIZE   = 5,
+    /* Resident 64-lane waves per compute unit launched by pipeline 1 (default 12). */
+    RT_OPT_WAVES_PER_CU = 6
 };
 
 /* ---- device context ------------------------------------------------------ */
@@ -125,6 +130,12 @@ int rt_resolve(rt_ctx* ctx, int total_frames);
  * (the shader's bvhNodeTests/triangleTests in reference traversal order, plus
  * the number of GetHit calls). Synchronises. */
 int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out);
+
+/* Diagnostics of the wave-scheduled kernel (no counterpart in the reference): renders the
+ * dispatch without writing images and returns, for step kind k = 0 object, 1 inner node,
+ * 2 triangle, 3 shade: out[2k] = wave-level executions of that step, out[2k+1] = lanes that
+ * took part (out[2k+1] / (64*out[2k]) is the lane utilisation of the step); out[8] = waves. */
+int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16]);
 
 /* Milliseconds the last rt_render_frame(s) call spent on the device, measured
  * with HIP events on the stream the kernels were launched on. Synchronises. */

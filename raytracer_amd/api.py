@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 MODELS_DIR = os.path.join(os.path.dirname(_HERE), "assets", "models")
 
 RT_IMAGE_DRAW, RT_IMAGE_ACCUM = 0, 1
-RT_OPT_FAST_MATH, RT_OPT_PIPELINE, RT_OPT_TILE_RANK, RT_OPT_TILE_WORLD, RT_OPT_TILE_SIZE = 1, 2, 3, 4, 5
+RT_OPT_FAST_MATH, RT_OPT_PIPELINE, RT_OPT_TILE_RANK, RT_OPT_TILE_WORLD, RT_OPT_TILE_SIZE, RT_OPT_WAVES_PER_CU = 1, 2, 3, 4, 5, 6
 
 
 class RtError(RuntimeError):
@@ -128,6 +128,7 @@ def load_library():
         "rt_render_frame": (ci, [vp, P(PushConstants)]), "rt_render_frames": (ci, [vp, P(PushConstants), ci, ci, ci]),
         "rt_sync": (ci, [vp]), "rt_read_image": (ci, [vp, ci, vp, C.c_size_t]), "rt_write_accum": (ci, [vp, vp, C.c_size_t]),
         "rt_resolve": (ci, [vp, ci]), "rt_frame_stats_compute": (ci, [vp, P(PushConstants), P(FrameStats)]),
+        "rt_schedule_stats": (ci, [vp, P(PushConstants), P(C.c_uint64)]),
         "rt_last_render_ms": (ci, [vp, P(cf), P(cf)]), "rt_image_size": (ci, [vp, P(ci), P(ci)]),
         "rt_last_error": (C.c_char_p, [vp]), "rt_version": (C.c_char_p, []),
         "rt_camera_to_push_constants": (ci, [P(CameraSettings), ci, ci, P(PushConstants)]),
@@ -154,7 +155,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_set_stream", "rt_set_option", "rt_get_option", "rt_upload_scene", "rt_resize",
     "rt_bind_images", "rt_clear_accumulation", "rt_render_frame", "rt_render_frames", "rt_sync", "rt_read_image",
-    "rt_write_accum", "rt_resolve", "rt_frame_stats_compute", "rt_last_render_ms", "rt_image_size", "rt_last_error",
+    "rt_write_accum", "rt_resolve", "rt_frame_stats_compute", "rt_schedule_stats", "rt_last_render_ms", "rt_image_size", "rt_last_error",
     "rt_version", "rt_camera_to_push_constants", "rt_default_push_constants", "rt_default_camera", "rt_default_material",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_last_error", "rt_scene_add_material", "rt_scene_material_index",
     "rt_scene_load_model", "rt_scene_add_object", "rt_scene_set_object", "rt_scene_set_material", "rt_scene_buffer_data",
@@ -330,6 +331,11 @@ class Renderer:
         st = FrameStats()
         self._check(self.lib.rt_frame_stats_compute(self.h, C.byref(pc), C.byref(st)))
         return st
+
+    def schedule_stats(self, pc):
+        out = (C.c_uint64 * 16)()
+        self._check(self.lib.rt_schedule_stats(self.h, C.byref(pc), out))
+        return [int(v) for v in out]
 
     def last_render_ms(self):
         a, b = C.c_float(), C.c_float()

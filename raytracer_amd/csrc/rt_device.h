@@ -28,6 +28,8 @@
 
 #define RT_REF_ABSENT ((int32_t)0x80000000)      /* child index was -1: not counted, not visited */
 #define RT_REF_EMPTY  ((int32_t)0x80000001)      /* leaf with zero triangles: counted, nothing to test */
+#define RT_REF_DEAD   ((int32_t)0x80000002)      /* child whose box has min > max on an axis: counted, no ray can enter it */
+#define RT_REF_LIVE_MIN ((int32_t)0x80000002)    /* references above this value can be entered */
 #define RT_MAX_STACK  32                         /* the shader's `int stack[32]` (raytrace.comp:523) */
 
 struct DevObject {
@@ -69,6 +71,12 @@ struct DevScene {
     const DevTri*      tris;
     const DevNrm*      nrms;
     const DevMaterial* materials;
+    /* Visiting order for rays that only ask "is anything hit" (shadow rays): leaf parents
+     * first, BVH parents after. anyOrder[p] = object at position p; nextAny[j] = object that
+     * follows object j (objectCount at the end); anyFirst = anyOrder[0]. */
+    const int32_t*     anyOrder;
+    const int32_t*     nextAny;
+    int32_t            anyFirst;
     int32_t            objectCount;   /* number of DevObject records uploaded */
     int32_t            stackDepth;    /* entries of traversal stack a lane can need (<= RT_MAX_STACK) */
 };

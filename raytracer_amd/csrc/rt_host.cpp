@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -30,6 +31,10 @@ hipError_t rt_launch_megakernel_strict(const DevScene*, const rt_push_constants*
                                        DevCounters*, int, int, hipStream_t);
 hipError_t rt_launch_megakernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
                                      DevCounters*, int, int, hipStream_t);
+hipError_t rt_launch_schedkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
+                                        DevCounters*, int, int, unsigned long long*, int, hipStream_t, unsigned long long*);
+hipError_t rt_launch_schedkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
+                                      DevCounters*, int, int, unsigned long long*, int, hipStream_t, unsigned long long*);
 hipError_t rt_launch_resolve_strict(const void*, void*, size_t, float, hipStream_t);
 hipError_t rt_launch_resolve_fast(const void*, void*, size_t, float, hipStream_t);
 }
@@ -49,6 +54,7 @@ struct rt_ctx {
     void* dTris = nullptr;
     void* dNrms = nullptr;
     void* dMaterials = nullptr;
+    void* dAnyOrder = nullptr;
     bool haveScene = false;
     size_t sceneBytes = 0;
 
@@ -60,6 +66,9 @@ struct rt_ctx {
     void* accum = nullptr;
 
     DevCounters* dCounters = nullptr;
+    unsigned long long* dQueue = nullptr;   // pixel counter of the wave-scheduled kernel
+    int computeUnits = 0;
+    int wavesPerCU = 12;
 
     int optFast = 0, optPipeline = 0, tileRank = 0, tileWorld = 1, tileSize = 64;
     std::string error;
@@ -89,7 +98,7 @@ int failHip(rt_ctx* ctx, hipError_t e, const char* what)
 
 void freeScene(rt_ctx* c)
 {
-    for (void** p : { &c->dObjects, &c->dNodes, &c->dTris, &c->dNrms, &c->dMaterials }) {
+    for (void** p : { &c->dObjects, &c->dNodes, &c->dTris, &c->dNrms, &c->dMaterials, &c->dAnyOrder }) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -215,6 +224,11 @@ struct Relayout {
         };
         box(first, n.fmin, n.fmax);
         box(second, n.smin, n.smax);
+        // a box with min > max on an axis can never be entered (raytrace.comp:221,239): keep it
+        // counted but dead, so the kernels may take the slab interval by min/max of the planes
+        auto inverted = [](const float mn[3], const float mx[3]) { return mn[0] > mx[0] || mn[1] > mx[1] || mn[2] > mx[2]; };
+        if (fr != RT_REF_ABSENT && inverted(n.fmin, n.fmax)) fr = RT_REF_DEAD;
+        if (sr != RT_REF_ABSENT && inverted(n.smin, n.smax)) sr = RT_REF_DEAD;
         n.first = fr;
         n.second = sr;
         dNodes[idx] = n;
@@ -257,6 +271,7 @@ struct Relayout {
                 int h;
                 if (!innerRef(p.node.rightChild, p.node.leftChild, 1, d.root, h)) return false;
             }
+            if (d.bmin[0] > d.bmax[0] || d.bmin[1] > d.bmax[1] || d.bmin[2] > d.bmax[2]) d.root = RT_REF_DEAD;
             dObjects[i] = d;
         }
         return true;
@@ -300,17 +315,29 @@ int checkRenderable(rt_ctx* ctx, const rt_push_constants* pc)
     if (pc->renderMode == 0 || pc->renderMode == 3 || pc->renderMode == 4) {
         if (pc->raysPerPixel < 0) return fail(ctx, RT_ERR_INVALID_ARG, "raysPerPixel is negative");
     }
-    if (ctx->optPipeline != 0) return fail(ctx, RT_ERR_UNSUPPORTED, "the wavefront pipeline is not built into this library");
     return RT_OK;
 }
 
-int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly)
+int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsigned long long* diag = nullptr)
 {
     const DevLaunch L = makeLaunch(ctx);
     const bool countBuild = statsOnly || pc.renderMode == 3 || pc.renderMode == 4;
-    auto fn = ctx->optFast ? rt_launch_megakernel_fast : rt_launch_megakernel_strict;
-    hipError_t e = fn(&ctx->scene, &pc, &L, ctx->accum, ctx->draw, statsOnly ? ctx->dCounters : nullptr, countBuild ? 1 : 0,
-                      statsOnly ? 1 : 0, ctx->stream);
+    const bool pathTrace = pc.renderMode == 0 || pc.renderMode == 3 || pc.renderMode == 4;
+    hipError_t e;
+    if (ctx->optPipeline == 1 && pathTrace && pc.raysPerPixel >= 1) {
+        // persistent grid: enough 64-lane blocks to fill every CU; lanes pull pixels from a counter
+        const long long wavesNeeded = ((long long)L.ownedTiles * L.tileSize * L.tileSize + 63) / 64;
+        const long long resident = (long long)std::max(1, ctx->computeUnits) * ctx->wavesPerCU;
+        const int blocks = (int)std::max<long long>(1, std::min(wavesNeeded, resident));
+        auto fn = ctx->optFast ? rt_launch_schedkernel_fast : rt_launch_schedkernel_strict;
+        e = fn(&ctx->scene, &pc, &L, ctx->accum, ctx->draw, statsOnly ? ctx->dCounters : nullptr, countBuild ? 1 : 0,
+               statsOnly ? 1 : 0, ctx->dQueue, blocks, ctx->stream, diag);
+    } else {
+        // the depth / box views and the degenerate raysPerPixel <= 0 case stay on the lock-step kernel
+        auto fn = ctx->optFast ? rt_launch_megakernel_fast : rt_launch_megakernel_strict;
+        e = fn(&ctx->scene, &pc, &L, ctx->accum, ctx->draw, statsOnly ? ctx->dCounters : nullptr, countBuild ? 1 : 0,
+               statsOnly ? 1 : 0, ctx->stream);
+    }
     if (e != hipSuccess) return failHip(ctx, e, "kernel launch");
     return RT_OK;
 }
@@ -336,7 +363,9 @@ int rt_create(int device_id, rt_ctx** out_ctx)
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
-        (e = hipMalloc((void**)&c->dCounters, sizeof(DevCounters))) != hipSuccess) {
+        (e = hipMalloc((void**)&c->dCounters, sizeof(DevCounters))) != hipSuccess ||
+        (e = hipMalloc((void**)&c->dQueue, 256)) != hipSuccess ||
+        (e = hipDeviceGetAttribute(&c->computeUnits, hipDeviceAttributeMultiprocessorCount, device_id)) != hipSuccess) {
         int rc = failHip(nullptr, e, "rt_create");
         rt_destroy(c);
         return rc;
@@ -354,6 +383,7 @@ void rt_destroy(rt_ctx* c)
     freeScene(c);
     freeImages(c);
     if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->dQueue) (void)hipFree(c->dQueue);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -376,8 +406,12 @@ int rt_set_option(rt_ctx* ctx, int option, int value)
     switch (option) {
     case RT_OPT_FAST_MATH: ctx->optFast = value ? 1 : 0; return RT_OK;
     case RT_OPT_PIPELINE:
-        if (value != 0) return fail(ctx, RT_ERR_UNSUPPORTED, "only pipeline 0 (megakernel) is available");
-        ctx->optPipeline = 0;
+        if (value != 0 && value != 1) return fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step megakernel) or 1 (wave-scheduled megakernel)");
+        ctx->optPipeline = value;
+        return RT_OK;
+    case RT_OPT_WAVES_PER_CU:
+        if (value < 1 || value > 32) return fail(ctx, RT_ERR_INVALID_ARG, "waves per CU must be in [1,32]");
+        ctx->wavesPerCU = value;
         return RT_OK;
     case RT_OPT_TILE_RANK:
         if (value < 0) return fail(ctx, RT_ERR_INVALID_ARG, "tile rank must be >= 0");
@@ -401,6 +435,7 @@ int rt_get_option(rt_ctx* ctx, int option, int* value)
     switch (option) {
     case RT_OPT_FAST_MATH: *value = ctx->optFast; return RT_OK;
     case RT_OPT_PIPELINE: *value = ctx->optPipeline; return RT_OK;
+    case RT_OPT_WAVES_PER_CU: *value = ctx->wavesPerCU; return RT_OK;
     case RT_OPT_TILE_RANK: *value = ctx->tileRank; return RT_OK;
     case RT_OPT_TILE_WORLD: *value = ctx->tileWorld; return RT_OK;
     case RT_OPT_TILE_SIZE: *value = ctx->tileSize; return RT_OK;
@@ -426,6 +461,22 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
         if (v->count != 0 && v->data == nullptr) return fail(ctx, RT_ERR_INVALID_ARG, "a non-empty buffer view has a null pointer");
     if (T >= 0x7ffffff0u || N >= 0x7ffffff0u) return fail(ctx, RT_ERR_SCENE_INVALID, "scene too large for 32-bit indices");
 
+    {
+        auto finite = [](const void* p, size_t vec4s) {
+            const float* f = static_cast<const float*>(p);
+            for (size_t i = 0; i < vec4s; ++i)
+                for (int k = 0; k < 3; ++k)
+                    if (!std::isfinite(f[4 * i + k])) return false;
+            return true;
+        };
+        if (!finite(b->aabbMins.data, N) || !finite(b->aabbMaxs.data, N))
+            return fail(ctx, RT_ERR_SCENE_INVALID, "a BVH node box has a non-finite coordinate");
+        const rt_parent_bvh_node* pp = static_cast<const rt_parent_bvh_node*>(b->parentBVH.data);
+        for (size_t i = 0; i < b->parentBVH.count; ++i)
+            for (int k = 0; k < 3; ++k)
+                if (!std::isfinite(pp[i].node.aabb.min[k]) || !std::isfinite(pp[i].node.aabb.max[k]))
+                    return fail(ctx, RT_ERR_SCENE_INVALID, "a parent box has a non-finite coordinate");
+    }
     Relayout rl(*b);
     if (!rl.run()) return fail(ctx, RT_ERR_SCENE_INVALID, rl.error);
 
@@ -449,6 +500,18 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
     if ((rc = uploadArray(ctx, &ctx->dTris, rl.dTris.data(), rl.dTris.size() * sizeof(DevTri))) != RT_OK) return rc;
     if ((rc = uploadArray(ctx, &ctx->dNrms, nrms.data(), nrms.size() * sizeof(DevNrm))) != RT_OK) return rc;
     if ((rc = uploadArray(ctx, &ctx->dMaterials, b->materials.data, b->materials.count * sizeof(DevMaterial))) != RT_OK) return rc;
+    // order in which "any hit" rays visit the objects: leaf parents (a handful of triangles, no
+    // walk) before BVH parents; both groups keep their scene order
+    const int32_t P = (int32_t)rl.dObjects.size();
+    std::vector<int32_t> anyOrder, orderTables(2 * (size_t)P + 2, P);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int32_t i = 0; i < P; ++i)
+            if ((rl.dObjects[i].root >= 0) == (pass == 1)) anyOrder.push_back(i);
+    for (int32_t p = 0; p < P; ++p) {
+        orderTables[p] = anyOrder[p];                                         // anyOrder
+        orderTables[P + 1 + anyOrder[p]] = p + 1 < P ? anyOrder[p + 1] : P;   // nextAny
+    }
+    if ((rc = uploadArray(ctx, &ctx->dAnyOrder, orderTables.data(), orderTables.size() * sizeof(int32_t))) != RT_OK) return rc;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die at return
 
     ctx->scene.objects = static_cast<const DevObject*>(ctx->dObjects);
@@ -456,6 +519,9 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
     ctx->scene.tris = static_cast<const DevTri*>(ctx->dTris);
     ctx->scene.nrms = static_cast<const DevNrm*>(ctx->dNrms);
     ctx->scene.materials = static_cast<const DevMaterial*>(ctx->dMaterials);
+    ctx->scene.anyOrder = static_cast<const int32_t*>(ctx->dAnyOrder);
+    ctx->scene.nextAny = static_cast<const int32_t*>(ctx->dAnyOrder) + P + 1;
+    ctx->scene.anyFirst = P > 0 ? anyOrder[0] : 0;
     ctx->scene.objectCount = (int32_t)rl.dObjects.size();
     ctx->scene.stackDepth = std::max(1, std::min(RT_MAX_STACK, rl.maxDepth));
     ctx->sceneBytes = rl.dObjects.size() * sizeof(DevObject) + rl.dNodes.size() * sizeof(DevNode) + rl.dTris.size() * sizeof(DevTri) +
@@ -597,6 +663,22 @@ int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_st
     out->bvhNodeTests = h.nodeTests;
     out->triangleTests = h.triTests;
     out->samples = h.samples;
+    return RT_OK;
+}
+
+int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16])
+{
+    int rc = checkRenderable(ctx, pc);
+    if (rc != RT_OK) return rc;
+    if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "null output pointer");
+    if (ctx->optPipeline != 1 || !(pc->renderMode == 0) || pc->raysPerPixel < 1)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "schedule statistics exist for pipeline 1, render mode 0 only");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long* d = ctx->dQueue + 8;   // the queue allocation is 256 bytes: counter + 16 statistics words
+    RT_HIP(ctx, hipMemsetAsync(d, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    if ((rc = launchFrame(ctx, *pc, true, d)) != RT_OK) return rc;
+    RT_HIP(ctx, hipMemcpyAsync(out, d, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 

@@ -141,7 +141,12 @@ __device__ __forceinline__ SlabRay make_slab_ray(V3 o, V3 d)
 }
 
 // One axis of IntersectAABB. For a parallel axis the interval is left alone and
-// only containment is checked, exactly as the shader does.
+// only containment is checked, exactly as the shader does. PAR = false is the
+// build for rays with no parallel axis (the caller checks that wave-wide).
+// fmaxf/fminf stand in for the GLSL max/min forms: their first operand (the
+// running interval bound) is never NaN, so both forms return the same value up
+// to the sign of a zero, and only comparisons consume the result.
+template <bool PAR>
 __device__ __forceinline__ void slab_axis(float o, float inv, bool neg, bool par, float mn, float mx,
                                           float& tEnter, float& tExit, bool& ok)
 {
@@ -149,29 +154,36 @@ __device__ __forceinline__ void slab_axis(float o, float inv, bool neg, bool par
     float t1 = (mx - o) * inv;
     float lo = neg ? t1 : t0;
     float hi = neg ? t0 : t1;
-    bool inside = !(o < mn || o > mx);
-    lo = par ? -INFINITY : lo;
-    hi = par ? INFINITY : hi;
-    ok = ok && (!par || inside);
-    tEnter = gmax(tEnter, lo);
-    tExit = gmin(tExit, hi);
+    if (PAR) {
+        bool inside = !(o < mn || o > mx);
+        lo = par ? -INFINITY : lo;
+        hi = par ? INFINITY : hi;
+        ok = ok && (!par || inside);
+    }
+    tEnter = fmaxf(tEnter, lo);
+    tExit = fminf(tExit, hi);
 }
 
 // IntersectAABB split in two: the part that does not depend on the current
-// closest hit (returned: ok, entry distance E with tMin folded in, exit T1), and
-// the part that does (C > E), which the caller applies at the moment the
-// reference would run the test. The shader's per-axis early-outs
+// closest hit (returned: ok, entry distance E with tMin folded in), and the
+// part that does (C > E), which the caller applies at the moment the reference
+// would run the test. The shader's per-axis early-outs
 // `if (t.max <= t.min) return false` are equivalent to the single final test
 // min(C,T1) > E because t.min only grows and t.max only shrinks.
-__device__ __forceinline__ bool slab_box(const SlabRay& r, V3 mn, V3 mx, float tMin, float& E)
+template <bool PAR>
+__device__ __forceinline__ bool slab_box_t(const SlabRay& r, V3 mn, V3 mx, float tMin, float& E)
 {
     float e = tMin, x = INFINITY;
     bool ok = true;
-    slab_axis(r.o.x, r.inv.x, r.negx, r.parx, mn.x, mx.x, e, x, ok);
-    slab_axis(r.o.y, r.inv.y, r.negy, r.pary, mn.y, mx.y, e, x, ok);
-    slab_axis(r.o.z, r.inv.z, r.negz, r.parz, mn.z, mx.z, e, x, ok);
+    slab_axis<PAR>(r.o.x, r.inv.x, r.negx, r.parx, mn.x, mx.x, e, x, ok);
+    slab_axis<PAR>(r.o.y, r.inv.y, r.negy, r.pary, mn.y, mx.y, e, x, ok);
+    slab_axis<PAR>(r.o.z, r.inv.z, r.negz, r.parz, mn.z, mx.z, e, x, ok);
     E = e;
     return ok && (x > e);
+}
+__device__ __forceinline__ bool slab_box(const SlabRay& r, V3 mn, V3 mx, float tMin, float& E)
+{
+    return slab_box_t<true>(r, mn, mx, tMin, E);
 }
 
 // raytrace.comp:345-355
@@ -222,7 +234,12 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
 
     const SlabRay wr = make_slab_ray(org, dirN);
 
-    for (int i = 0; i < parentCount; ++i) {
+    // A ray that only asks whether anything is hit keeps closestSoFar at tMax until its first
+    // accepted hit, so which triangles it can reach does not depend on the visiting order: it
+    // may take the cheap leaf parents first. (Only when the dispatch covers every uploaded parent.)
+    const bool permute = ANYHIT && parentCount == S.objectCount;
+    for (int pos = 0; pos < parentCount; ++pos) {
+        const int i = permute ? S.anyOrder[pos] : pos;
         const DevObject* ob = S.objects + i;   // wave-uniform address
         if (COUNT) cnt.nodeTests++;
         V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
@@ -230,7 +247,7 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
         bool ok = slab_box(wr, bmn, bmx, tMin, E) && (best.closest > E);
         if (ok) ok = !(distance_to_aabb(org, bmn, bmx) > best.closest);
         int cur = ob->root;
-        if (!ok || cur == RT_REF_EMPTY || cur == RT_REF_ABSENT) continue;
+        if (!ok || !(cur > RT_REF_LIVE_MIN)) continue;
 
         V3 lo = xform(ob->inv, org, 1.0f);
         V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
@@ -247,8 +264,8 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
                 bool okS = slab_box(lr, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
                 bool presF = refs.x != RT_REF_ABSENT, presS = refs.y != RT_REF_ABSENT;
                 if (COUNT) cnt.nodeTests += (presF ? 1 : 0) + (presS ? 1 : 0);
-                bool goF = presF && okF && (best.closest > EF) && refs.x != RT_REF_EMPTY;
-                bool canS = presS && okS && refs.y != RT_REF_EMPTY;
+                bool goF = refs.x > RT_REF_LIVE_MIN && okF && (best.closest > EF);
+                bool canS = refs.y > RT_REF_LIVE_MIN && okS;
                 if (goF) {
                     if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(ES)); ++sp; }
                     cur = refs.x;
@@ -623,6 +640,457 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_megakernel)(DevScene S, rt_push_
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Wave-scheduled persistent megakernel.
+//
+// The lock-step kernel above keeps all 64 lanes inside the same GetHit call, so a
+// wave pays for its slowest lane in every loop (PMC: 16 % of VALU lanes active).
+// Here every lane carries its own small state machine over the same arithmetic:
+//   K_OBJECT  GetHit's object loop: parent boxes until one is entered (+ ray
+//             set-up at the first object)
+//   K_INNER   one two-child BVH record
+//   K_TRI     one triangle of a leaf
+//   K_SHADE   everything between two GetHit calls: hit record, emission, sun
+//             term, scatter, sample / pixel book-keeping, fetching a new pixel
+// and the wave repeatedly votes (ballot + popcount) for the step kind that most
+// lanes are waiting for and executes only that one. Lanes of a finished path take
+// the next pixel from a global counter, so a wave stays full until the image is
+// done. A pixel is owned by one lane for all its samples, which keeps the
+// reference's in-order accumulation (raytrace.comp:779-792).
+//
+// The loop-carried state is kept free of booleans (they would live in scalar
+// register pairs and spill): a ray's slab constants are just origin and
+// reciprocal direction. The "invD < 0" swap of raytrace.comp:230-236 is taken
+// by min/max of the two plane distances, which is the same thing for a box with
+// min <= max (the upload marks inverted boxes, which no ray can hit, as dead),
+// and an axis with abs(dir) < 1e-8 gets a NaN reciprocal, which makes both
+// plane distances NaN and leaves the interval untouched in fmaxf/fminf exactly
+// as the shader's parallel branch does; its containment test runs in a separate
+// wave-uniform slow path.
+enum : int { F_HAVE_PATH = 1, F_SHADOW = 2, F_PAR_WORLD = 4, F_PAR_LOCAL = 8 };
+
+struct LeanRay { V3 o, inv; };
+
+// Reciprocal direction with NaN on axes the shader treats as parallel; returns
+// whether any axis is.
+__device__ __forceinline__ bool lean_inverse(V3 d, V3& inv)
+{
+    const bool px = fabsf(d.x) < 1e-8f, py = fabsf(d.y) < 1e-8f, pz = fabsf(d.z) < 1e-8f;
+    const float nan = __int_as_float(0x7fc00000);
+    inv.x = px ? nan : 1.0f / d.x;
+    inv.y = py ? nan : 1.0f / d.y;
+    inv.z = pz ? nan : 1.0f / d.z;
+    return px || py || pz;
+}
+
+template <bool PAR>
+__device__ __forceinline__ bool lean_box(V3 o, V3 inv, V3 mn, V3 mx, float tMin, float& E)
+{
+    float e = tMin, x = INFINITY;
+    bool ok = true;
+    {
+        float t0 = (mn.x - o.x) * inv.x, t1 = (mx.x - o.x) * inv.x;
+        e = fmaxf(e, fminf(t0, t1)); x = fminf(x, fmaxf(t0, t1));
+        if (PAR) ok = ok && !((inv.x != inv.x) && (o.x < mn.x || o.x > mx.x));
+    }
+    {
+        float t0 = (mn.y - o.y) * inv.y, t1 = (mx.y - o.y) * inv.y;
+        e = fmaxf(e, fminf(t0, t1)); x = fminf(x, fmaxf(t0, t1));
+        if (PAR) ok = ok && !((inv.y != inv.y) && (o.y < mn.y || o.y > mx.y));
+    }
+    {
+        float t0 = (mn.z - o.z) * inv.z, t1 = (mx.z - o.z) * inv.z;
+        e = fmaxf(e, fminf(t0, t1)); x = fminf(x, fmaxf(t0, t1));
+        if (PAR) ok = ok && !((inv.z != inv.z) && (o.z < mn.z || o.z > mx.z));
+    }
+    E = e;
+    return ok && (x > e);
+}
+
+// Per-lane traversal state of the scheduled kernel.
+struct LaneTrace {
+    V3 rayO, dirN;      // world ray (dirN normalised)
+    V3 lo, ld, linv;    // ray in the space of object `obj`, reciprocal direction (NaN = parallel axis)
+    float closest, bestT, bestU, bestV;
+    int bestObj, bestTri;
+    int obj;            // index in the parent array
+    int cur;            // K_TRAV: >= 0 two-child record, < 0 leaf triangle ~cur
+    int sp;
+};
+
+// One triangle: IntersectTriangle (raytrace.comp:278-328) plus the acceptance test of
+// raytrace.comp:559-572. Returns true when the hit was accepted.
+__device__ __forceinline__ bool lane_triangle(const DevScene& S, LaneTrace& t, const float* fwd, int triIndex, float tMin, int& remaining)
+{
+    const float4* tp = reinterpret_cast<const float4*>(S.tris + triIndex);
+    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+    remaining = __float_as_int(t0.w);
+    V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
+    V3 h = cross3(t.ld, e2);
+    float det = dot3(e1, h);
+    const float eps = 1e-5f;
+    bool accepted = false;
+    if (!(fabsf(det) < eps)) {
+        float invDet = 1.0f / det;
+        V3 s = t.lo - v0;
+        float u = invDet * dot3(s, h);
+        V3 sc = cross3(s, e1);
+        float v = invDet * dot3(t.ld, sc);
+        bool miss = (u < -eps || u > 1.0f + eps) || (v < -eps || u + v > 1.0f + eps);
+        float hitT = invDet * dot3(e2, sc);
+        if (!miss && (hitT >= tMin && hitT <= t.closest) && hitT > eps) {
+            const float4* fp = reinterpret_cast<const float4*>(fwd);
+            float4 f0 = fp[0], f1 = fp[1], f2 = fp[2];
+            V3 p = t.lo + t.ld * hitT;
+            V3 wp = mk((f0.x * p.x + f0.y * p.y) + (f0.z * p.z + f0.w * 1.0f),
+                       (f1.x * p.x + f1.y * p.y) + (f1.z * p.z + f1.w * 1.0f),
+                       (f2.x * p.x + f2.y * p.y) + (f2.z * p.z + f2.w * 1.0f));
+            float worldT = dot3(wp - t.rayO, t.dirN);
+            if (worldT > tMin && worldT < t.closest) {
+                t.closest = worldT;
+                t.bestT = hitT;
+                t.bestU = u; t.bestV = v;
+                t.bestObj = t.obj;
+                t.bestTri = __float_as_int(t1.w);
+                accepted = true;
+            }
+        }
+    }
+    return accepted;
+}
+
+// Next stack entry whose box still reaches inside the closest hit, or RT_NONE.
+__device__ __forceinline__ int lane_pop(LaneTrace& t, const uint2* stack)
+{
+    while (t.sp > 0) {
+        --t.sp;
+        uint2 e = stack[t.sp * 64];
+        if (t.closest > __uint_as_float(e.y)) return (int)e.x;
+    }
+    return RT_NONE;
+}
+
+enum : int { K_OBJECT = 0, K_TRAV = 1, K_SHADE = 2, K_IDLE = 3 };
+
+template <bool COUNT, bool DIAG>
+__global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
+                                                            float4* __restrict__ accum, float4* __restrict__ out,
+                                                            DevCounters* counters, int statsOnly,
+                                                            unsigned long long* __restrict__ queue,
+                                                            unsigned long long* __restrict__ diag)
+{
+    extern __shared__ uint2 stackMem[];
+    const int lane = threadIdx.x;
+    uint2* stack = stackMem + lane;
+
+    const int bounces = pc.maxBounces + 1;
+    const int parentCount = pc.parentBVHCount;
+    const int rpp = pc.raysPerPixel;
+    const int mode = pc.renderMode;
+    const float tMin = 0.001f;
+    const int wavesX = L.tileSize >> 3;
+    const unsigned pixelsPerTile = (unsigned)L.tileSize * (unsigned)L.tileSize;
+    const unsigned long long totalPixels = (unsigned long long)L.ownedTiles * pixelsPerTile;
+    // shadow rays may visit leaf parents first (see trace()); not in the counting build, whose
+    // counters are those of the reference order
+    const bool permute = !COUNT && parentCount == S.objectCount;
+
+    // ---- per-lane state (no booleans) ----
+    int state = K_SHADE, flags = 0;
+    int px = 0, py = 0, sample = 0, bounce = 0;
+    uint32_t seed0 = 0;
+    V3 nc = mk(0.0f, 0.0f, 0.0f);            // newColour.rgb of the pixel
+    V3 result = mk(0.0f, 0.0f, 0.0f), throughput = mk(1.0f, 1.0f, 1.0f);
+    V3 rayD = mk(0.0f, 0.0f, 1.0f);
+    V3 winv = mk(1.0f, 1.0f, 1.0f);
+    V3 pendD = mk(0.0f, 0.0f, 0.0f);          // sun term waiting for its shadow ray
+    V3 pendO = mk(0.0f, 0.0f, 0.0f), pendDir = rayD;   // scattered ray waiting behind the shadow ray
+    LaneTrace t;
+    t.rayO = mk(0.0f, 0.0f, 0.0f); t.dirN = rayD; t.lo = t.rayO; t.ld = rayD; t.linv = winv;
+    t.closest = 1e20f; t.bestT = t.bestU = t.bestV = 0.0f; t.bestObj = -1; t.bestTri = 0;
+    t.obj = -1; t.cur = 0; t.sp = 0;
+    int cRays = 0, cNode = 0, cTri = 0;
+    long long totRays = 0, totNode = 0, totTri = 0, totSamples = 0;
+    unsigned long long dExec[4] = { 0, 0, 0, 0 }, dLanes[4] = { 0, 0, 0, 0 };   // wave-uniform
+
+    for (;;) {
+        // ---- vote: which kind of round next ----
+        const int nO = __popcll(__ballot(state == K_OBJECT));
+        const int nT = __popcll(__ballot(state == K_TRAV));
+        const int nS = __popcll(__ballot(state == K_SHADE));
+        if ((nO | nT | nS) == 0) break;
+        int kind;
+        if (nT >= 32 || (nT > 0 && nT >= nO && nT >= nS)) kind = K_TRAV;
+        else if (nO >= nS) kind = K_OBJECT;
+        else kind = K_SHADE;
+
+        if (kind == K_TRAV) {
+            // BVH round: the lanes inside a BVH walk it together until too few of them are left
+            const int quorum = nT >= 32 ? 16 : (nT + 1) / 2;
+            for (;;) {
+                const int active = __popcll(__ballot(state == K_TRAV));
+                if (DIAG) { dExec[K_TRAV] += 1; dLanes[K_TRAV] += active; }
+                if (active < quorum || active == 0) break;
+                if (state == K_TRAV) {
+                    int next = t.cur;
+                    if (t.cur >= 0) {
+                        const float4* np = reinterpret_cast<const float4*>(S.nodes + t.cur);
+                        float4 a = np[0], b = np[1], c = np[2];
+                        int2 refs = *reinterpret_cast<const int2*>(np + 3);
+                        float EF, ES;
+                        bool okF, okS;
+                        if (__any(flags & F_PAR_LOCAL)) {
+                            okF = lean_box<true>(t.lo, t.linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
+                            okS = lean_box<true>(t.lo, t.linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
+                        } else {
+                            okF = lean_box<false>(t.lo, t.linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
+                            okS = lean_box<false>(t.lo, t.linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
+                        }
+                        if (COUNT) cNode += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
+                        const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (t.closest > EF);
+                        const bool canS = refs.y > RT_REF_LIVE_MIN && okS;
+                        if (goF) {
+                            if (canS) { stack[t.sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(ES)); ++t.sp; }
+                            next = refs.x;
+                        } else if (canS && (t.closest > ES)) {
+                            next = refs.y;
+                        } else {
+                            next = lane_pop(t, stack);
+                        }
+                    } else {
+                        int remaining;
+                        if (COUNT) cTri++;
+                        const bool hit = lane_triangle(S, t, S.objects[t.obj].fwd, ~t.cur, tMin, remaining);
+                        if (!COUNT && hit && (flags & F_SHADOW)) { state = K_SHADE; }   // any hit settles a shadow ray
+                        else if (remaining <= 1) next = lane_pop(t, stack);
+                        else next = t.cur - 1;   // ~(k+1)
+                    }
+                    if (next == RT_NONE) {
+                        if (state == K_TRAV) {
+                            t.obj = (permute && (flags & F_SHADOW)) ? S.nextAny[t.obj] : t.obj + 1;
+                            state = t.obj < parentCount ? K_OBJECT : K_SHADE;
+                        }
+                    }
+                    else t.cur = next;
+                }
+            }
+        } else if (kind == K_OBJECT) {
+            // object round: the waiting lanes walk the parent array together (wave-uniform index, so
+            // the parent record and a leaf parent's triangles come through scalar loads); a lane
+            // joins at the object it is at, tests leaf parents on the spot and leaves the round
+            // when it enters a BVH parent, whose walk is left to a BVH round
+            if (DIAG) { dExec[K_OBJECT] += 1; dLanes[K_OBJECT] += nO; }
+            if (state == K_OBJECT && t.obj < 0) {
+                // start of GetHit, raytrace.comp:450-456
+                t.dirN = normalize3(rayD);
+                flags = lean_inverse(t.dirN, winv) ? (flags | F_PAR_WORLD) : (flags & ~F_PAR_WORLD);
+                t.closest = 1e20f;
+                t.bestObj = -1;
+                t.obj = (permute && (flags & F_SHADOW)) ? S.anyFirst : 0;
+                if (COUNT) cRays++;
+            }
+            for (int j = 0; j < parentCount; ++j) {
+                const bool mine = state == K_OBJECT && t.obj == j;
+                if (!__any(mine)) continue;
+                const DevObject* ob = S.objects + j;   // wave-uniform
+                const int root = ob->root;
+                const int nextShadow = permute ? S.nextAny[j] : j + 1;
+                if (mine) {
+                    const int nextObj = (flags & F_SHADOW) ? nextShadow : j + 1;
+                    if (COUNT) cNode++;
+                    V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+                    float E;
+                    bool ok = ((flags & F_PAR_WORLD) ? lean_box<true>(t.rayO, winv, bmn, bmx, tMin, E)
+                                                     : lean_box<false>(t.rayO, winv, bmn, bmx, tMin, E)) && (t.closest > E);
+                    if (ok) ok = !(distance_to_aabb(t.rayO, bmn, bmx) > t.closest);
+                    t.obj = nextObj;
+                    if (ok && root > RT_REF_LIVE_MIN) {
+                        t.lo = xform(ob->inv, t.rayO, 1.0f);
+                        t.ld = normalize3(xform(ob->inv, t.dirN, 0.0f));
+                        t.sp = 0;
+                        if (root >= 0) {
+                            flags = lean_inverse(t.ld, t.linv) ? (flags | F_PAR_LOCAL) : (flags & ~F_PAR_LOCAL);
+                            t.obj = j;
+                            t.cur = root;
+                            state = K_TRAV;
+                        } else {
+                            // leaf parent, raytrace.comp:488-520
+                            t.obj = j;
+                            int k = ~root, remaining;
+                            for (;;) {
+                                if (COUNT) cTri++;
+                                const bool hit = lane_triangle(S, t, ob->fwd, k, tMin, remaining);
+                                if (!COUNT && hit && (flags & F_SHADOW)) { state = K_SHADE; break; }
+                                if (remaining <= 1) break;
+                                ++k;
+                            }
+                            t.obj = nextObj;
+                        }
+                    }
+                }
+            }
+            if (state == K_OBJECT && t.obj >= parentCount) state = K_SHADE;
+        } else {   // K_SHADE
+            if (DIAG) { dExec[K_SHADE] += 1; dLanes[K_SHADE] += nS; }
+            if (state == K_SHADE) {
+                int pathEnd = 1;
+                if (flags & F_HAVE_PATH) {
+                    pathEnd = 0;
+                    int startTrace = 0;
+                    if (flags & F_SHADOW) {
+                        // back from ShadowTransmission, raytrace.comp:733-753
+                        if (t.bestObj < 0) result = result + pendD;
+                        flags &= ~F_SHADOW;
+                        t.rayO = pendO; rayD = pendDir;
+                        ++bounce;
+                        if (bounce < bounces) startTrace = 1; else pathEnd = 1;
+                    } else {
+                        Best best;
+                        best.closest = t.closest; best.tLocal = t.bestT; best.u = t.bestU; best.v = t.bestV;
+                        best.object = t.bestObj; best.tri = t.bestTri;
+                        HitRec rec;
+                        finish_hit(S, t.rayO, t.dirN, best, rec);
+                        if (!rec.hit) {
+                            result = result + throughput * environment_colour(pc, rayD);
+                            pathEnd = 1;
+                        } else if (!rec.frontFace) {
+                            pathEnd = 1;
+                        } else {
+                            DevMaterial m = load_material(S, rec.matIndex);
+                            V3 emitted = ld3(m.colour) * m.emission;
+                            result = result + throughput * emitted;
+                            if (m.emission > 0.0f) {
+                                pathEnd = 1;
+                            } else {
+                                V3 negSun = -ld3(pc.sunDirection);
+                                float nDotL = gmax(dot3(rec.normal, negSun), 0.0f);
+                                V3 attenuation;
+                                Ray scattered;
+                                material_scatter(m, rayD, rec, seed0, attenuation, scattered);
+                                if (nDotL > 0.0f) {
+                                    V3 sun = ld3(pc.sunColour) * pc.sunIntensity;
+                                    const float INV_PI = 0.31830988618f;
+                                    V3 direct = sun * (nDotL * INV_PI);
+                                    if (m.refractionIndex == 0.0f) pendD = (throughput * ld3(m.colour)) * direct;
+                                    else pendD = (throughput * reflectance(nDotL, m.refractionIndex)) * direct;
+                                    pendO = scattered.o; pendDir = scattered.d;
+                                    t.rayO = rec.point + rec.normal * 0.01f;
+                                    rayD = negSun;
+                                    flags |= F_SHADOW;
+                                    startTrace = 1;
+                                } else {
+                                    t.rayO = scattered.o; rayD = scattered.d;
+                                    ++bounce;
+                                    if (bounce < bounces) startTrace = 1; else pathEnd = 1;
+                                }
+                                throughput = throughput * attenuation;
+                            }
+                        }
+                    }
+                    if (startTrace) { t.obj = -1; state = K_OBJECT; }
+                }
+                if (pathEnd) {
+                    if (flags & F_HAVE_PATH) {
+                        // end of one RayColour call, raytrace.comp:784
+                        nc = nc + result;
+                        ++sample;
+                        if (sample >= rpp) {
+                            // rest of Pathtrace, raytrace.comp:787-816
+                            const size_t idx = (size_t)py * (size_t)L.width + (size_t)px;
+                            if (!statsOnly) {
+                                if (mode == 0) {
+                                    float raysPerPixelRatio = 1.0f / (float)rpp;
+                                    float accumulationMultiplier = pc.accumulateFrames == 1 ? 1.0f / (float)(pc.frame + 1) : 1.0f;
+                                    float4 acc = accum[idx];
+                                    V3 ncs = nc * raysPerPixelRatio;
+                                    acc.x += ncs.x; acc.y += ncs.y; acc.z += ncs.z;
+                                    accum[idx] = acc;
+                                    float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(ncs.x, ncs.y, ncs.z, 1.0f);
+                                    avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
+                                    out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
+                                } else {
+                                    int threshold = mode == 3 ? pc.triangleTestThreshold : pc.bvhNodeTestThreshold;
+                                    int target = mode == 3 ? cTri : cNode;
+                                    int grey = (int)((float)target / (float)threshold * 255.0f);
+                                    grey = grey < 0 ? 0 : (grey > 255 ? 255 : grey);
+                                    float g = (float)grey / 255.0f;
+                                    float4 c = make_float4(g, g, g, 1.0f);
+                                    if (cTri > threshold) c = make_float4(1.0f, 0.0f, 0.0f, 1.0f);
+                                    out[idx] = c;
+                                }
+                            }
+                            if (COUNT) { totRays += cRays; totNode += cNode; totTri += cTri; totSamples += sample; }
+                            flags &= ~F_HAVE_PATH;
+                        }
+                    }
+                    // lanes without a pixel take the next ones from the global counter
+                    while (!(flags & F_HAVE_PATH) && state != K_IDLE) {
+                        const unsigned long long need = __ballot(1);
+                        const int n = __popcll(need);
+                        const int leader = __ffsll((long long)need) - 1;
+                        unsigned long long base = 0;
+                        if (lane == leader) base = atomicAdd(queue, (unsigned long long)n);
+                        base = (unsigned long long)__shfl((long long)base, leader, 64);
+                        const unsigned long long idx = base + (unsigned long long)__popcll(need & ((1ull << lane) - 1ull));
+                        if (idx >= totalPixels) {
+                            state = K_IDLE;
+                        } else {
+                            const unsigned ownedTile = (unsigned)(idx / pixelsPerTile);
+                            const unsigned local = (unsigned)(idx - (unsigned long long)ownedTile * pixelsPerTile);
+                            const int tile = L.tileRank + (int)ownedTile * L.tileWorld;
+                            const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
+                            const int sub = (int)(local >> 6), l = (int)(local & 63u);
+                            const int sy = sub / wavesX, sx = sub - sy * wavesX;
+                            px = tx * L.tileSize + sx * 8 + (l & 7);
+                            py = ty * L.tileSize + sy * 8 + (l >> 3);
+                            if (px < L.width && py < L.height) {
+                                flags |= F_HAVE_PATH;
+                                sample = 0;
+                                nc = mk(0.0f, 0.0f, 0.0f);
+                                cRays = cNode = cTri = 0;
+                            }
+                        }
+                    }
+                    if (flags & F_HAVE_PATH) {
+                        // next sample of the pixel, raytrace.comp:781-783
+                        seed0 = seed_from_coords((uint32_t)px, (uint32_t)py, (uint32_t)pc.frame, (uint32_t)sample);
+                        Ray r0 = get_ray(pc, px, py, seed0);
+                        t.rayO = r0.o; rayD = r0.d;
+                        result = mk(0.0f, 0.0f, 0.0f);
+                        throughput = mk(1.0f, 1.0f, 1.0f);
+                        bounce = 0;
+                        flags &= ~F_SHADOW;
+                        t.obj = -1;
+                        state = K_OBJECT;
+                    }
+                }
+            }
+        }
+    }
+
+    if (DIAG && diag != nullptr && lane == 0) {
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(&diag[2 * k], dExec[k]);
+            atomicAdd(&diag[2 * k + 1], dLanes[k]);
+        }
+        atomicAdd(&diag[8], 1ull);
+    }
+    if (COUNT && counters != nullptr) {
+        for (int off = 32; off > 0; off >>= 1) {
+            totRays += __shfl_down(totRays, off, 64);
+            totNode += __shfl_down(totNode, off, 64);
+            totTri += __shfl_down(totTri, off, 64);
+            totSamples += __shfl_down(totSamples, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters->rays, (unsigned long long)totRays);
+            atomicAdd(&counters->nodeTests, (unsigned long long)totNode);
+            atomicAdd(&counters->triTests, (unsigned long long)totTri);
+            atomicAdd(&counters->samples, (unsigned long long)totSamples);
+        }
+    }
+}
+
 // draw = gamma(accum.rgb * 1/total_frames), draw.a = accum.a (raytrace.comp:794-801)
 __global__ __launch_bounds__(256) void RT_SYM(rt_resolve_kernel)(const float4* __restrict__ accum, float4* __restrict__ out,
                                                                  size_t pixels, float multiplier)
@@ -664,5 +1132,27 @@ extern "C" hipError_t RT_SYM(rt_launch_resolve)(const void* accum, void* out, si
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(RT_SYM(rt_resolve_kernel), dim3((unsigned)blocks), dim3(256), 0, stream, (const float4*)accum,
                        (float4*)out, pixels, multiplier);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t RT_SYM(rt_launch_schedkernel)(const DevScene* S, const rt_push_constants* pc, const DevLaunch* L,
+                                                    void* accum, void* out, DevCounters* counters, int countBuild,
+                                                    int statsOnly, unsigned long long* queue, int blocks, hipStream_t stream,
+                                                    unsigned long long* diag)
+{
+    if (L->ownedTiles <= 0 || blocks <= 0) return hipSuccess;
+    const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
+    hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)blocks), block(64);
+    if (diag)
+        hipLaunchKernelGGL((RT_SYM(rt_schedkernel)<false, true>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum,
+                           (float4*)out, counters, statsOnly, queue, diag);
+    else if (countBuild)
+        hipLaunchKernelGGL((RT_SYM(rt_schedkernel)<true, false>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum,
+                           (float4*)out, counters, statsOnly, queue, diag);
+    else
+        hipLaunchKernelGGL((RT_SYM(rt_schedkernel)<false, false>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum,
+                           (float4*)out, counters, statsOnly, queue, diag);
     return hipGetLastError();
 }

@@ -38,12 +38,27 @@ pc.renderMode = 0
 # timing probe at 2560x1369
 W2, H2 = 2560, 1369
 r.resize(W2, H2); R.camera_to_push_constants(cam, W2, H2, pc)
-for fast in (0, 1):
-    r.set_option(R.RT_OPT_FAST_MATH, fast)
-    r.render_frames(pc, 0, 1, 2); r.sync()
-    r.clear_accumulation()
-    t = time.time(); r.render_frames(pc, 0, 1, 8); r.sync(); dt = time.time() - t
-    ms_total, ms_per = r.last_render_ms()
-    pc.frame = 0
-    st = r.frame_stats(pc)
-    print("fast=%d 2560x1369: %.2f ms/frame (events %.2f), rays/frame %d -> %.1f Mrays/s" % (fast, dt / 8 * 1e3, ms_per, st.rays, st.rays / (ms_per * 1e-3) / 1e6))
+for pipe in (0, 1):
+    r.set_option(R.RT_OPT_PIPELINE, pipe)
+    for fast in (0, 1):
+        r.set_option(R.RT_OPT_FAST_MATH, fast)
+        r.render_frames(pc, 0, 1, 2); r.sync()
+        r.clear_accumulation()
+        r.render_frames(pc, 0, 1, 8); r.sync()
+        ms_total, ms_per = r.last_render_ms()
+        pc.frame = 0
+        st = r.frame_stats(pc)
+        print("pipeline=%d fast=%d 2560x1369: %.2f ms/frame, rays/frame %d -> %.1f Mrays/s" % (pipe, fast, ms_per, st.rays, st.rays / (ms_per * 1e-3) / 1e6))
+r.set_option(R.RT_OPT_PIPELINE, 1); r.set_option(R.RT_OPT_FAST_MATH, 0)
+for w in (4, 8, 10, 12, 16):
+    r.set_option(R.RT_OPT_WAVES_PER_CU, w)
+    r.render_frames(pc, 0, 1, 8); r.sync()
+    print("waves/CU %d: %.2f ms/frame" % (w, r.last_render_ms()[1]))
+r.set_option(R.RT_OPT_WAVES_PER_CU, 12)
+pc.frame = 0
+d = r.schedule_stats(pc)
+names = ["object", "trav", "shade", "-"]
+tot = sum(d[2 * k] for k in range(4))
+for k in range(4):
+    print("%-7s execs %12d (%.1f%%)  lanes/exec %.1f" % (names[k], d[2 * k], 100.0 * d[2 * k] / tot, d[2 * k + 1] / max(1, d[2 * k])))
+print("waves", d[8], "iterations/wave", tot / max(1, d[8]))

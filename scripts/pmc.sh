@@ -12,7 +12,7 @@ import csv, sys, collections
 f = sys.argv[1]
 acc = collections.defaultdict(lambda: [0.0, 0])
 for row in csv.DictReader(open(f)):
-    if 'rt_megakernel' not in row['Kernel_Name']: continue
+    if 'kernel' not in row['Kernel_Name'] or 'resolve' in row['Kernel_Name'] or not row['Kernel_Name'].startswith(('void rt_', 'rt_')): continue
     acc[row['Counter_Name']][0] += float(row['Counter_Value']); acc[row['Counter_Name']][1] += 1
 for k, (v, n) in sorted(acc.items()):
     print("%-32s per-dispatch %.6g (n=%d)" % (k, v / n, n))
