@@ -96,16 +96,12 @@ def main():
     r = R.Renderer(local_rank)
     r.upload_scene(sb)
     r.set_option(R.RT_OPT_FAST_MATH, args.fast)
-    draw = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()
-    r.bind_images(draw.data_ptr(), accum.data_ptr(), W, H)
-    r.set_stream(torch.cuda.current_stream().cuda_stream)
-
     pc = R.default_push_constants()
     R.camera_to_push_constants(R.default_camera(), W, H, pc)
     pc.parentBVHCount = 8
-    frames = [rank + k * world for k in range(spp)]
+    from raytracer_amd import distributed as D
+    target = D.GpuTarget(r, pc, W, H, dev)      # images are torch tensors, kernels run on torch's stream
+    frames = D.frames_of_rank(rank, world, spp)
 
     # untimed counting pass: GetHit calls and the shader's node/triangle test counters per frame
     rays = node = tri = 0
@@ -120,11 +116,9 @@ def main():
     total_rays = float(counts[0].item())
 
     def step():
-        accum.zero_()
-        r.render_frames(pc, rank, world, spp)
-        if distributed:
-            dist.all_reduce(accum)
-        r.resolve(spp * world)
+        # clear, `spp` dispatches (frames rank, rank+N, ...), one all-reduce of the accumulation
+        # image when N > 1, resolve
+        D.render_sample_split(target, spp)
 
     def fence():
         torch.cuda.synchronize()
@@ -185,7 +179,7 @@ def main():
             p0.frame = 0
             out["cpu_baseline"] = cpu_baseline(arrays, p0.as_bytes, W, H, args.cpu_seconds, threads)
         print(json.dumps(out), flush=True)
-    r.set_stream(None)
+    target.close()
     r.close()
     if distributed:
         dist.barrier()

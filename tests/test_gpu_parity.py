@@ -29,9 +29,11 @@ def R():
     return raytracer_amd
 
 
-@pytest.fixture(scope="module")
-def rdr(R, default_scene_arrays):
+@pytest.fixture(scope="module", params=[0, 1], ids=["lockstep", "scheduled"])
+def rdr(R, default_scene_arrays, request):
+    """One renderer per kernel choice: every test that takes `rdr` runs on both pipelines."""
     r = R.Renderer(0)
+    r.set_option(R.RT_OPT_PIPELINE, request.param)
     r.upload_scene(default_scene_arrays)
     yield r
     r.close()
@@ -203,13 +205,15 @@ def test_converged_psnr(R, rdr, default_scene_arrays):
     assert psnr >= 45.0, psnr
 
 
-def test_mixed_material_scene(R):
+@pytest.mark.parametrize("pipeline", [0, 1], ids=["lockstep", "scheduled"])
+def test_mixed_material_scene(R, pipeline):
     """Glass (exp/pow), mirror, fuzzy metal, emitter, open sky (acos/exp/pow), sub-unit and
     non-uniform scales, a model without normals and one with a 287-triangle leaf."""
     materials, objects = scenes.mixed_recipe()
     arrays = scenes.build_oracle(materials, objects).bindings()
     r = R.Renderer(0)
     try:
+        r.set_option(R.RT_OPT_PIPELINE, pipeline)
         r.upload_scene(arrays)
         W, H = 256, 144
         opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 2.5, 8.0), look=(0.0, -0.15, -1.0), fov=60.0, maxBounces=5)
@@ -371,6 +375,32 @@ def test_bound_images(R, rdr, default_scene_arrays):
     finally:
         rdr.set_stream(None)
         rdr.bind_images(None, None, 0, 0)
+
+
+def test_distributed_driver_single_rank(R, default_scene_arrays):
+    """raytracer_amd.distributed on one GPU (world size 1): the GpuTarget plumbing (torch-owned
+    images, torch's stream, tile options) and both drivers against the oracle."""
+    import torch
+    from raytracer_amd import distributed as D
+    W, H = 112, 64
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays)
+        opc = scenes.make_pc(default_scene_arrays, W, H)
+        tgt = D.GpuTarget(r, to_pc(R, opc), W, H, "cuda:0")
+        assert D.render_sample_split(tgt, 3) == 3
+        torch.cuda.synchronize()
+        o = oracle_frames(default_scene_arrays, opc, [0, 1, 2], W, H)
+        assert np.array_equal(bits(tgt.accum.cpu().numpy()), bits(o["accum"]))
+        assert np.array_equal(bits(tgt.draw.cpu().numpy()), bits(o["out"]))
+        D.render_tile_split(tgt, 2, tile_size=32)
+        torch.cuda.synchronize()
+        o = oracle_frames(default_scene_arrays, opc, [0, 1], W, H)
+        assert np.array_equal(bits(tgt.accum.cpu().numpy()), bits(o["accum"]))
+        assert np.array_equal(bits(tgt.draw.cpu().numpy()), bits(o["out"]))
+        tgt.close()
+    finally:
+        r.close()
 
 
 def test_error_paths(R, default_scene_arrays):
