@@ -50,9 +50,10 @@ enum {
     RT_OPT_FAST_MATH   = 1,
     /* Kernel that renders modes 0/3/4. 0 (default) = lock-step megakernel: one lane per pixel,
      * the 64 lanes of a wave walk the same GetHit call together. 1 = wave-scheduled persistent
-     * megakernel: every lane runs its own state machine, the wave votes which kind of round
-     * (object loop / BVH walk / shading) to run next, finished lanes pull new pixels from a
-     * global counter. Same arithmetic, same results. */
+     * megakernel: every lane runs its own state machine, the wave votes whether to run a BVH
+     * round (only the lanes inside a BVH walk step) or an object/shade iteration (everything
+     * else) next, finished lanes pull new pixels from a global counter. Same arithmetic, same
+     * results. */
     RT_OPT_PIPELINE    = 2,
     /* Tile partition for multi-GPU tile split: this context renders only the
      * tiles t with t % RT_OPT_TILE_WORLD == RT_OPT_TILE_RANK (tiles are
@@ -62,7 +63,13 @@ enum {
     RT_OPT_TILE_WORLD  = 4,
     RT_OPT_TILE_SIZE   = 5,
     /* Resident 64-lane waves per compute unit launched by pipeline 1 (default 12). */
-    RT_OPT_WAVES_PER_CU = 6
+    RT_OPT_WAVES_PER_CU = 6,
+    /* Round selection of pipeline 1 (tuning knobs, results do not depend on them): a BVH round
+     * runs when (walking lanes - BIAS_TRAV) >= (other lanes - BIAS_SHADE); it ends when fewer
+     * than max(min(QUORUM_MIN, lanes_at_start), lanes_at_start / QUORUM_DIV) lanes are still
+     * walking. BIAS_OBJECT is reserved. */
+    RT_OPT_SCHED_BIAS_OBJECT = 7, RT_OPT_SCHED_BIAS_TRAV = 8, RT_OPT_SCHED_BIAS_SHADE = 9,
+    RT_OPT_SCHED_QUORUM_MIN = 10, RT_OPT_SCHED_QUORUM_DIV = 11
 };
 
 /* ---- device context ------------------------------------------------------ */
@@ -132,9 +139,9 @@ int rt_resolve(rt_ctx* ctx, int total_frames);
 int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out);
 
 /* Diagnostics of the wave-scheduled kernel (no counterpart in the reference): renders the
- * dispatch without writing images and returns, for step kind k = 0 object, 1 inner node,
- * 2 triangle, 3 shade: out[2k] = wave-level executions of that step, out[2k+1] = lanes that
- * took part (out[2k+1] / (64*out[2k]) is the lane utilisation of the step); out[8] = waves. */
+ * dispatch without writing images and returns, for k = 0 object/shade iterations and k = 1
+ * BVH-round steps: out[2k] = wave-level executions, out[2k+1] = lanes that took part
+ * (out[2k+1] / (64*out[2k]) is the lane participation); out[8] = waves. */
 int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16]);
 
 /* Milliseconds the last rt_render_frame(s) call spent on the device, measured

@@ -73,10 +73,12 @@ struct DevScene {
     const DevMaterial* materials;
     /* Visiting order for rays that only ask "is anything hit" (shadow rays): leaf parents
      * first, BVH parents after. anyOrder[p] = object at position p; nextAny[j] = object that
-     * follows object j (objectCount at the end); anyFirst = anyOrder[0]. */
+     * follows object j (objectCount at the end); anyFirst = anyOrder[0]; anyLeafCount = number
+     * of leaf parents = position of the first BVH parent in anyOrder. */
     const int32_t*     anyOrder;
     const int32_t*     nextAny;
     int32_t            anyFirst;
+    int32_t            anyLeafCount;
     int32_t            objectCount;   /* number of DevObject records uploaded */
     int32_t            stackDepth;    /* entries of traversal stack a lane can need (<= RT_MAX_STACK) */
 };
@@ -87,6 +89,9 @@ struct DevLaunch {
     int32_t tilesX, tilesY;
     int32_t tileRank, tileWorld;
     int32_t ownedTiles;    /* number of tiles t with t % tileWorld == tileRank */
+    /* round selection of the wave-scheduled kernel: the kind with the largest (waiting lanes -
+     * bias) runs; a BVH round ends when fewer than max(quorumMin, started/quorumDiv) lanes walk */
+    int32_t biasObject, biasTrav, biasShade, quorumMin, quorumDiv;
 };
 
 struct DevCounters {

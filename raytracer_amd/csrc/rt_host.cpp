@@ -69,6 +69,7 @@ struct rt_ctx {
     unsigned long long* dQueue = nullptr;   // pixel counter of the wave-scheduled kernel
     int computeUnits = 0;
     int wavesPerCU = 12;
+    int policy[5] = { 0, 0, 0, 4, 8 };   // biasObject, biasTrav, biasShade, quorumMin, quorumDiv
 
     int optFast = 0, optPipeline = 0, tileRank = 0, tileWorld = 1, tileSize = 64;
     std::string error;
@@ -300,6 +301,8 @@ DevLaunch makeLaunch(const rt_ctx* c)
     L.tileWorld = c->tileWorld;
     const int total = L.tilesX * L.tilesY;
     L.ownedTiles = total > c->tileRank ? (total - c->tileRank + c->tileWorld - 1) / c->tileWorld : 0;
+    L.biasObject = c->policy[0]; L.biasTrav = c->policy[1]; L.biasShade = c->policy[2];
+    L.quorumMin = std::max(1, c->policy[3]); L.quorumDiv = std::max(1, c->policy[4]);
     return L;
 }
 
@@ -406,12 +409,17 @@ int rt_set_option(rt_ctx* ctx, int option, int value)
     switch (option) {
     case RT_OPT_FAST_MATH: ctx->optFast = value ? 1 : 0; return RT_OK;
     case RT_OPT_PIPELINE:
-        if (value != 0 && value != 1) return fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step megakernel) or 1 (wave-scheduled megakernel)");
+        if (value < 0 || value > 1) return fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step) or 1 (wave-scheduled)");
         ctx->optPipeline = value;
         return RT_OK;
     case RT_OPT_WAVES_PER_CU:
         if (value < 1 || value > 32) return fail(ctx, RT_ERR_INVALID_ARG, "waves per CU must be in [1,32]");
         ctx->wavesPerCU = value;
+        return RT_OK;
+    case RT_OPT_SCHED_BIAS_OBJECT: case RT_OPT_SCHED_BIAS_TRAV: case RT_OPT_SCHED_BIAS_SHADE:
+    case RT_OPT_SCHED_QUORUM_MIN: case RT_OPT_SCHED_QUORUM_DIV:
+        if (value < -64 || value > 64) return fail(ctx, RT_ERR_INVALID_ARG, "scheduling parameter out of range");
+        ctx->policy[option - RT_OPT_SCHED_BIAS_OBJECT] = value;
         return RT_OK;
     case RT_OPT_TILE_RANK:
         if (value < 0) return fail(ctx, RT_ERR_INVALID_ARG, "tile rank must be >= 0");
@@ -522,6 +530,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
     ctx->scene.anyOrder = static_cast<const int32_t*>(ctx->dAnyOrder);
     ctx->scene.nextAny = static_cast<const int32_t*>(ctx->dAnyOrder) + P + 1;
     ctx->scene.anyFirst = P > 0 ? anyOrder[0] : 0;
+    ctx->scene.anyLeafCount = 0;
+    for (int i = 0; i < P; ++i) ctx->scene.anyLeafCount += rl.dObjects[i].root < 0 ? 1 : 0;
     ctx->scene.objectCount = (int32_t)rl.dObjects.size();
     ctx->scene.stackDepth = std::max(1, std::min(RT_MAX_STACK, rl.maxDepth));
     ctx->sceneBytes = rl.dObjects.size() * sizeof(DevObject) + rl.dNodes.size() * sizeof(DevNode) + rl.dTris.size() * sizeof(DevTri) +

@@ -207,6 +207,53 @@ __device__ __forceinline__ V3 xform(const float* m, V3 v, float w)
               (m[8] * v.x + m[9] * v.y) + (m[10] * v.z + m[11] * w));
 }
 
+// The slab test in the form the kernels use. A ray's constants are just origin and
+// reciprocal direction. The "invD < 0" swap of raytrace.comp:230-236 is taken by min/max of
+// the two plane distances, which is the same thing for a box with min <= max (the upload marks
+// inverted boxes, which no ray can enter, as dead), and an axis with abs(dir) < 1e-8 gets a NaN
+// reciprocal, which makes both plane distances NaN and leaves the interval untouched in
+// fmaxf/fminf exactly as the shader's parallel branch does; its containment test only runs
+// in the PAR = true build, which callers select wave-wide when some lane has such an axis.
+enum : int { F_HAVE_PATH = 1, F_SHADOW = 2, F_PAR_WORLD = 4, F_PAR_LOCAL = 8 };
+
+struct LeanRay { V3 o, inv; };
+
+// Reciprocal direction with NaN on axes the shader treats as parallel; returns
+// whether any axis is.
+__device__ __forceinline__ bool lean_inverse(V3 d, V3& inv)
+{
+    const bool px = fabsf(d.x) < 1e-8f, py = fabsf(d.y) < 1e-8f, pz = fabsf(d.z) < 1e-8f;
+    const float nan = __int_as_float(0x7fc00000);
+    inv.x = px ? nan : 1.0f / d.x;
+    inv.y = py ? nan : 1.0f / d.y;
+    inv.z = pz ? nan : 1.0f / d.z;
+    return px || py || pz;
+}
+
+template <bool PAR>
+__device__ __forceinline__ bool lean_box(V3 o, V3 inv, V3 mn, V3 mx, float tMin, float& E)
+{
+    float e = tMin, x = INFINITY;
+    bool ok = true;
+    {
+        float t0 = (mn.x - o.x) * inv.x, t1 = (mx.x - o.x) * inv.x;
+        e = fmaxf(e, fminf(t0, t1)); x = fminf(x, fmaxf(t0, t1));
+        if (PAR) ok = ok && !((inv.x != inv.x) && (o.x < mn.x || o.x > mx.x));
+    }
+    {
+        float t0 = (mn.y - o.y) * inv.y, t1 = (mx.y - o.y) * inv.y;
+        e = fmaxf(e, fminf(t0, t1)); x = fminf(x, fmaxf(t0, t1));
+        if (PAR) ok = ok && !((inv.y != inv.y) && (o.y < mn.y || o.y > mx.y));
+    }
+    {
+        float t0 = (mn.z - o.z) * inv.z, t1 = (mx.z - o.z) * inv.z;
+        e = fmaxf(e, fminf(t0, t1)); x = fminf(x, fmaxf(t0, t1));
+        if (PAR) ok = ok && !((inv.z != inv.z) && (o.z < mn.z || o.z > mx.z));
+    }
+    E = e;
+    return ok && (x > e);
+}
+
 struct Counters { int rays, nodeTests, triTests; };
 
 // What a GetHit call keeps while it walks: enough to rebuild the RayHit.
@@ -232,7 +279,8 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
     best.tri = 0; best.u = 0.0f; best.v = 0.0f; best.tLocal = 0.0f;
     if (COUNT) cnt.rays++;
 
-    const SlabRay wr = make_slab_ray(org, dirN);
+    V3 winv;
+    const bool parW = lean_inverse(dirN, winv);
 
     // A ray that only asks whether anything is hit keeps closestSoFar at tMax until its first
     // accepted hit, so which triangles it can reach does not depend on the visiting order: it
@@ -244,14 +292,17 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
         if (COUNT) cnt.nodeTests++;
         V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
         float E;
-        bool ok = slab_box(wr, bmn, bmx, tMin, E) && (best.closest > E);
+        bool ok = (__any(parW) ? lean_box<true>(org, winv, bmn, bmx, tMin, E) : lean_box<false>(org, winv, bmn, bmx, tMin, E)) &&
+                  (best.closest > E);
         if (ok) ok = !(distance_to_aabb(org, bmn, bmx) > best.closest);
         int cur = ob->root;
         if (!ok || !(cur > RT_REF_LIVE_MIN)) continue;
 
         V3 lo = xform(ob->inv, org, 1.0f);
         V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
-        const SlabRay lr = make_slab_ray(lo, ld);
+        V3 linv = ld;
+        bool parL = false;
+        if (cur >= 0) parL = lean_inverse(ld, linv);   // a leaf parent has no boxes to test
         int sp = 0;
 
         for (;;) {
@@ -260,10 +311,15 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
                 float4 a = np[0], b = np[1], c = np[2];
                 int2 refs = *reinterpret_cast<const int2*>(np + 3);
                 float EF, ES;
-                bool okF = slab_box(lr, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
-                bool okS = slab_box(lr, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
-                bool presF = refs.x != RT_REF_ABSENT, presS = refs.y != RT_REF_ABSENT;
-                if (COUNT) cnt.nodeTests += (presF ? 1 : 0) + (presS ? 1 : 0);
+                bool okF, okS;
+                if (__any(parL)) {
+                    okF = lean_box<true>(lo, linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
+                    okS = lean_box<true>(lo, linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
+                } else {
+                    okF = lean_box<false>(lo, linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
+                    okS = lean_box<false>(lo, linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
+                }
+                if (COUNT) cnt.nodeTests += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
                 bool goF = refs.x > RT_REF_LIVE_MIN && okF && (best.closest > EF);
                 bool canS = refs.y > RT_REF_LIVE_MIN && okS;
                 if (goF) {
@@ -277,6 +333,7 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
                 for (;;) {
                     const float4* tp = reinterpret_cast<const float4*>(S.tris + k);
                     float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    const int remaining = __float_as_int(t0.w);
                     if (COUNT) cnt.triTests++;
                     // IntersectTriangle, raytrace.comp:278-328
                     V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
@@ -306,7 +363,7 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
                             }
                         }
                     }
-                    if (__float_as_int(t0.w) <= 1) break;
+                    if (remaining <= 1) break;
                     ++k;
                 }
             }
@@ -645,18 +702,21 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_megakernel)(DevScene S, rt_push_
 //
 // The lock-step kernel above keeps all 64 lanes inside the same GetHit call, so a
 // wave pays for its slowest lane in every loop (PMC: 16 % of VALU lanes active).
-// Here every lane carries its own small state machine over the same arithmetic:
-//   K_OBJECT  GetHit's object loop: parent boxes until one is entered (+ ray
-//             set-up at the first object)
-//   K_INNER   one two-child BVH record
-//   K_TRI     one triangle of a leaf
-//   K_SHADE   everything between two GetHit calls: hit record, emission, sun
-//             term, scatter, sample / pixel book-keeping, fetching a new pixel
-// and the wave repeatedly votes (ballot + popcount) for the step kind that most
-// lanes are waiting for and executes only that one. Lanes of a finished path take
-// the next pixel from a global counter, so a wave stays full until the image is
-// done. A pixel is owned by one lane for all its samples, which keeps the
-// reference's in-order accumulation (raytrace.comp:779-792).
+// Here every lane carries its own small state machine over the same arithmetic and
+// is in one of two states:
+//   K_OS    outside a BVH walk: GetHit's object loop (parent boxes, leaf parents
+//           such as the six walls) and everything between two GetHit calls (hit
+//           record, emission, sun term, scatter, sample / pixel book-keeping,
+//           fetching a new pixel)
+//   K_TRAV  inside the walk of one BVH parent: ray into object space, then one
+//           two-child record or one triangle per step
+// The wave repeatedly votes (ballot + popcount) which of the two to run next. A BVH
+// round steps only the walking lanes and ends when fewer than a quorum are left;
+// the stragglers keep their place and continue in the next BVH round together with
+// the lanes that arrived meanwhile, so one long walk does not hold 63 lanes up.
+// Lanes of a finished path take the next pixel from a global counter, so a wave
+// stays full until the image is done. A pixel is owned by one lane for all its
+// samples, which keeps the reference's in-order accumulation (raytrace.comp:779-792).
 //
 // The loop-carried state is kept free of booleans (they would live in scalar
 // register pairs and spill): a ray's slab constants are just origin and
@@ -667,46 +727,6 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_megakernel)(DevScene S, rt_push_
 // plane distances NaN and leaves the interval untouched in fmaxf/fminf exactly
 // as the shader's parallel branch does; its containment test runs in a separate
 // wave-uniform slow path.
-enum : int { F_HAVE_PATH = 1, F_SHADOW = 2, F_PAR_WORLD = 4, F_PAR_LOCAL = 8 };
-
-struct LeanRay { V3 o, inv; };
-
-// Reciprocal direction with NaN on axes the shader treats as parallel; returns
-// whether any axis is.
-__device__ __forceinline__ bool lean_inverse(V3 d, V3& inv)
-{
-    const bool px = fabsf(d.x) < 1e-8f, py = fabsf(d.y) < 1e-8f, pz = fabsf(d.z) < 1e-8f;
-    const float nan = __int_as_float(0x7fc00000);
-    inv.x = px ? nan : 1.0f / d.x;
-    inv.y = py ? nan : 1.0f / d.y;
-    inv.z = pz ? nan : 1.0f / d.z;
-    return px || py || pz;
-}
-
-template <bool PAR>
-__device__ __forceinline__ bool lean_box(V3 o, V3 inv, V3 mn, V3 mx, float tMin, float& E)
-{
-    float e = tMin, x = INFINITY;
-    bool ok = true;
-    {
-        float t0 = (mn.x - o.x) * inv.x, t1 = (mx.x - o.x) * inv.x;
-        e = fmaxf(e, fminf(t0, t1)); x = fminf(x, fmaxf(t0, t1));
-        if (PAR) ok = ok && !((inv.x != inv.x) && (o.x < mn.x || o.x > mx.x));
-    }
-    {
-        float t0 = (mn.y - o.y) * inv.y, t1 = (mx.y - o.y) * inv.y;
-        e = fmaxf(e, fminf(t0, t1)); x = fminf(x, fmaxf(t0, t1));
-        if (PAR) ok = ok && !((inv.y != inv.y) && (o.y < mn.y || o.y > mx.y));
-    }
-    {
-        float t0 = (mn.z - o.z) * inv.z, t1 = (mx.z - o.z) * inv.z;
-        e = fmaxf(e, fminf(t0, t1)); x = fminf(x, fmaxf(t0, t1));
-        if (PAR) ok = ok && !((inv.z != inv.z) && (o.z < mn.z || o.z > mx.z));
-    }
-    E = e;
-    return ok && (x > e);
-}
-
 // Per-lane traversal state of the scheduled kernel.
 struct LaneTrace {
     V3 rayO, dirN;      // world ray (dirN normalised)
@@ -770,7 +790,8 @@ __device__ __forceinline__ int lane_pop(LaneTrace& t, const uint2* stack)
     return RT_NONE;
 }
 
-enum : int { K_OBJECT = 0, K_TRAV = 1, K_SHADE = 2, K_IDLE = 3 };
+enum : int { K_OS = 0, K_TRAV = 1, K_IDLE = 2 };
+#define RT_ENTER 0x7ffffffe   /* LaneTrace::cur: about to test the parent box of object `obj` */
 
 template <bool COUNT, bool DIAG>
 __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
@@ -796,7 +817,7 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
     const bool permute = !COUNT && parentCount == S.objectCount;
 
     // ---- per-lane state (no booleans) ----
-    int state = K_SHADE, flags = 0;
+    int state = K_OS, flags = 0;
     int px = 0, py = 0, sample = 0, bounce = 0;
     uint32_t seed0 = 0;
     V3 nc = mk(0.0f, 0.0f, 0.0f);            // newColour.rgb of the pixel
@@ -808,32 +829,44 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
     LaneTrace t;
     t.rayO = mk(0.0f, 0.0f, 0.0f); t.dirN = rayD; t.lo = t.rayO; t.ld = rayD; t.linv = winv;
     t.closest = 1e20f; t.bestT = t.bestU = t.bestV = 0.0f; t.bestObj = -1; t.bestTri = 0;
-    t.obj = -1; t.cur = 0; t.sp = 0;
+    t.obj = parentCount;                      // "trace complete": the first shade stage fetches a pixel
+    t.cur = RT_ENTER; t.sp = 0;
     int cRays = 0, cNode = 0, cTri = 0;
     long long totRays = 0, totNode = 0, totTri = 0, totSamples = 0;
-    unsigned long long dExec[4] = { 0, 0, 0, 0 }, dLanes[4] = { 0, 0, 0, 0 };   // wave-uniform
+    unsigned long long dExec[2] = { 0, 0 }, dLanes[2] = { 0, 0 };   // wave-uniform
 
     for (;;) {
-        // ---- vote: which kind of round next ----
-        const int nO = __popcll(__ballot(state == K_OBJECT));
+        // ---- vote: BVH round or object/shade iteration ----
         const int nT = __popcll(__ballot(state == K_TRAV));
-        const int nS = __popcll(__ballot(state == K_SHADE));
-        if ((nO | nT | nS) == 0) break;
-        int kind;
-        if (nT >= 32 || (nT > 0 && nT >= nO && nT >= nS)) kind = K_TRAV;
-        else if (nO >= nS) kind = K_OBJECT;
-        else kind = K_SHADE;
+        const int nS = __popcll(__ballot(state == K_OS));
+        if ((nT | nS) == 0) break;
 
-        if (kind == K_TRAV) {
-            // BVH round: the lanes inside a BVH walk it together until too few of them are left
-            const int quorum = nT >= 32 ? 16 : (nT + 1) / 2;
+        if (nT > 0 && (nS == 0 || nT - L.biasTrav >= nS - L.biasShade)) {
+            // BVH round: lanes walk the object whose box they entered; the round ends when fewer than
+            // the quorum are still at it - the stragglers keep their place and carry on in the next
+            // BVH round together with the lanes that arrive meanwhile
+            const int quorum = max(min(L.quorumMin, nT), nT / L.quorumDiv);
             for (;;) {
                 const int active = __popcll(__ballot(state == K_TRAV));
                 if (DIAG) { dExec[K_TRAV] += 1; dLanes[K_TRAV] += active; }
                 if (active < quorum || active == 0) break;
                 if (state == K_TRAV) {
                     int next = t.cur;
-                    if (t.cur >= 0) {
+                    if (t.cur == RT_ENTER) {
+                        // ray into the object's space, raytrace.comp:480-486
+                        const float4* op = reinterpret_cast<const float4*>(S.objects + t.obj);
+                        float4 b0 = op[0];
+                        float4 i0 = op[2], i1 = op[3], i2 = op[4];
+                        t.lo = mk((i0.x * t.rayO.x + i0.y * t.rayO.y) + (i0.z * t.rayO.z + i0.w * 1.0f),
+                                  (i1.x * t.rayO.x + i1.y * t.rayO.y) + (i1.z * t.rayO.z + i1.w * 1.0f),
+                                  (i2.x * t.rayO.x + i2.y * t.rayO.y) + (i2.z * t.rayO.z + i2.w * 1.0f));
+                        t.ld = normalize3(mk((i0.x * t.dirN.x + i0.y * t.dirN.y) + (i0.z * t.dirN.z + i0.w * 0.0f),
+                                             (i1.x * t.dirN.x + i1.y * t.dirN.y) + (i1.z * t.dirN.z + i1.w * 0.0f),
+                                             (i2.x * t.dirN.x + i2.y * t.dirN.y) + (i2.z * t.dirN.z + i2.w * 0.0f)));
+                        flags = lean_inverse(t.ld, t.linv) ? (flags | F_PAR_LOCAL) : (flags & ~F_PAR_LOCAL);
+                        t.sp = 0;
+                        next = __float_as_int(b0.w);
+                    } else if (t.cur >= 0) {
                         const float4* np = reinterpret_cast<const float4*>(S.nodes + t.cur);
                         float4 a = np[0], b = np[1], c = np[2];
                         int2 refs = *reinterpret_cast<const int2*>(np + 3);
@@ -861,78 +894,24 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
                         int remaining;
                         if (COUNT) cTri++;
                         const bool hit = lane_triangle(S, t, S.objects[t.obj].fwd, ~t.cur, tMin, remaining);
-                        if (!COUNT && hit && (flags & F_SHADOW)) { state = K_SHADE; }   // any hit settles a shadow ray
+                        if (!COUNT && hit && (flags & F_SHADOW)) { t.obj = parentCount; state = K_OS; }   // any hit settles a shadow ray
                         else if (remaining <= 1) next = lane_pop(t, stack);
                         else next = t.cur - 1;   // ~(k+1)
                     }
-                    if (next == RT_NONE) {
-                        if (state == K_TRAV) {
-                            t.obj = (permute && (flags & F_SHADOW)) ? S.nextAny[t.obj] : t.obj + 1;
-                            state = t.obj < parentCount ? K_OBJECT : K_SHADE;
-                        }
+                    if (next == RT_NONE) {   // this object is done: back to the object loop
+                        t.obj = (permute && (flags & F_SHADOW)) ? S.nextAny[t.obj] : t.obj + 1;
+                        state = K_OS;
                     }
-                    else t.cur = next;
+                    t.cur = next;
                 }
             }
-        } else if (kind == K_OBJECT) {
-            // object round: the waiting lanes walk the parent array together (wave-uniform index, so
-            // the parent record and a leaf parent's triangles come through scalar loads); a lane
-            // joins at the object it is at, tests leaf parents on the spot and leaves the round
-            // when it enters a BVH parent, whose walk is left to a BVH round
-            if (DIAG) { dExec[K_OBJECT] += 1; dLanes[K_OBJECT] += nO; }
-            if (state == K_OBJECT && t.obj < 0) {
-                // start of GetHit, raytrace.comp:450-456
-                t.dirN = normalize3(rayD);
-                flags = lean_inverse(t.dirN, winv) ? (flags | F_PAR_WORLD) : (flags & ~F_PAR_WORLD);
-                t.closest = 1e20f;
-                t.bestObj = -1;
-                t.obj = (permute && (flags & F_SHADOW)) ? S.anyFirst : 0;
-                if (COUNT) cRays++;
-            }
-            for (int j = 0; j < parentCount; ++j) {
-                const bool mine = state == K_OBJECT && t.obj == j;
-                if (!__any(mine)) continue;
-                const DevObject* ob = S.objects + j;   // wave-uniform
-                const int root = ob->root;
-                const int nextShadow = permute ? S.nextAny[j] : j + 1;
-                if (mine) {
-                    const int nextObj = (flags & F_SHADOW) ? nextShadow : j + 1;
-                    if (COUNT) cNode++;
-                    V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
-                    float E;
-                    bool ok = ((flags & F_PAR_WORLD) ? lean_box<true>(t.rayO, winv, bmn, bmx, tMin, E)
-                                                     : lean_box<false>(t.rayO, winv, bmn, bmx, tMin, E)) && (t.closest > E);
-                    if (ok) ok = !(distance_to_aabb(t.rayO, bmn, bmx) > t.closest);
-                    t.obj = nextObj;
-                    if (ok && root > RT_REF_LIVE_MIN) {
-                        t.lo = xform(ob->inv, t.rayO, 1.0f);
-                        t.ld = normalize3(xform(ob->inv, t.dirN, 0.0f));
-                        t.sp = 0;
-                        if (root >= 0) {
-                            flags = lean_inverse(t.ld, t.linv) ? (flags | F_PAR_LOCAL) : (flags & ~F_PAR_LOCAL);
-                            t.obj = j;
-                            t.cur = root;
-                            state = K_TRAV;
-                        } else {
-                            // leaf parent, raytrace.comp:488-520
-                            t.obj = j;
-                            int k = ~root, remaining;
-                            for (;;) {
-                                if (COUNT) cTri++;
-                                const bool hit = lane_triangle(S, t, ob->fwd, k, tMin, remaining);
-                                if (!COUNT && hit && (flags & F_SHADOW)) { state = K_SHADE; break; }
-                                if (remaining <= 1) break;
-                                ++k;
-                            }
-                            t.obj = nextObj;
-                        }
-                    }
-                }
-            }
-            if (state == K_OBJECT && t.obj >= parentCount) state = K_SHADE;
-        } else {   // K_SHADE
-            if (DIAG) { dExec[K_SHADE] += 1; dLanes[K_SHADE] += nS; }
-            if (state == K_SHADE) {
+        } else {
+            // object/shade iteration for the lanes outside the BVH walks: (S) shade every ray whose
+            // GetHit is complete and start the next ray, then (W) sweep the parent array with a
+            // wave-uniform index; lanes leave for the BVH rounds when they enter a BVH parent's box
+            if (DIAG) { dExec[K_OS] += 1; dLanes[K_OS] += nS; }
+            // ---- S: shade rays whose GetHit is complete, start the next ray ----
+            if (state == K_OS && t.obj >= parentCount) {
                 int pathEnd = 1;
                 if (flags & F_HAVE_PATH) {
                     pathEnd = 0;
@@ -987,7 +966,7 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
                             }
                         }
                     }
-                    if (startTrace) { t.obj = -1; state = K_OBJECT; }
+                    (void)startTrace;
                 }
                 if (pathEnd) {
                     if (flags & F_HAVE_PATH) {
@@ -1060,8 +1039,54 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
                         throughput = mk(1.0f, 1.0f, 1.0f);
                         bounce = 0;
                         flags &= ~F_SHADOW;
-                        t.obj = -1;
-                        state = K_OBJECT;
+                    }
+                }
+                if (state == K_OS) {
+                    // start of GetHit for the ray just made, raytrace.comp:450-456
+                    t.dirN = normalize3(rayD);
+                    flags = lean_inverse(t.dirN, winv) ? (flags | F_PAR_WORLD) : (flags & ~F_PAR_WORLD);
+                    t.closest = 1e20f;
+                    t.bestObj = -1;
+                    t.obj = (permute && (flags & F_SHADOW)) ? S.anyFirst : 0;
+                    if (COUNT) cRays++;
+                }
+            }
+            // ---- W: parent array in order; a second pass over the BVH parents serves the shadow rays,
+            // which take the leaf parents first ----
+            const int sweep = parentCount + (permute ? parentCount - S.anyLeafCount : 0);
+            for (int pos = 0; pos < sweep; ++pos) {
+                const int j = pos < parentCount ? pos : S.anyOrder[pos - parentCount + S.anyLeafCount];
+                const bool mine = state == K_OS && t.obj == j;
+                if (!__any(mine)) continue;
+                const DevObject* ob = S.objects + j;
+                const int root = ob->root;
+                const int nextShadow = permute ? S.nextAny[j] : j + 1;
+                if (mine) {
+                    const int nextObj = (flags & F_SHADOW) ? nextShadow : j + 1;
+                    if (COUNT) cNode++;
+                    V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+                    float E;
+                    bool ok = ((flags & F_PAR_WORLD) ? lean_box<true>(t.rayO, winv, bmn, bmx, tMin, E)
+                                                     : lean_box<false>(t.rayO, winv, bmn, bmx, tMin, E)) && (t.closest > E);
+                    if (ok) ok = !(distance_to_aabb(t.rayO, bmn, bmx) > t.closest);
+                    ok = ok && root > RT_REF_LIVE_MIN;
+                    if (!ok) {
+                        t.obj = nextObj;
+                    } else if (root >= 0) {
+                        state = K_TRAV; t.cur = RT_ENTER;   // BVH parent: walked in the BVH rounds
+                    } else {
+                        // leaf parent, raytrace.comp:488-520
+                        t.lo = xform(ob->inv, t.rayO, 1.0f);
+                        t.ld = normalize3(xform(ob->inv, t.dirN, 0.0f));
+                        int k = ~root, remaining;
+                        for (;;) {
+                            if (COUNT) cTri++;
+                            const bool hit = lane_triangle(S, t, ob->fwd, k, tMin, remaining);
+                            if (!COUNT && hit && (flags & F_SHADOW)) { remaining = -1; break; }
+                            if (remaining <= 1) break;
+                            ++k;
+                        }
+                        t.obj = remaining < 0 ? parentCount : nextObj;   // a shadow ray that hit is finished
                     }
                 }
             }
@@ -1069,7 +1094,7 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
     }
 
     if (DIAG && diag != nullptr && lane == 0) {
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
             atomicAdd(&diag[2 * k], dExec[k]);
             atomicAdd(&diag[2 * k + 1], dLanes[k]);
         }
