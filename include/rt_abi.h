@@ -53,7 +53,10 @@ enum {
      * megakernel: every lane runs its own state machine, the wave votes whether to run a BVH
      * round (only the lanes inside a BVH walk step) or an object/shade iteration (everything
      * else) next, finished lanes pull new pixels from a global counter. Same arithmetic, same
-     * results. */
+     * results. 2 = wavefront: a ray that enters the box of a BVH parent is suspended (state in
+     * HBM) and a second kernel, in which every lane takes the next ray as soon as its walk is
+     * done, finishes its GetHit; further rounds of the path kernel pick the paths up again.
+     * Needs 176 bytes of device memory per pixel. Same arithmetic, same results. */
     RT_OPT_PIPELINE    = 2,
     /* Tile partition for multi-GPU tile split: this context renders only the
      * tiles t with t % RT_OPT_TILE_WORLD == RT_OPT_TILE_RANK (tiles are
@@ -69,7 +72,11 @@ enum {
      * than max(min(QUORUM_MIN, lanes_at_start), lanes_at_start / QUORUM_DIV) lanes are still
      * walking. BIAS_OBJECT is reserved. */
     RT_OPT_SCHED_BIAS_OBJECT = 7, RT_OPT_SCHED_BIAS_TRAV = 8, RT_OPT_SCHED_BIAS_SHADE = 9,
-    RT_OPT_SCHED_QUORUM_MIN = 10, RT_OPT_SCHED_QUORUM_DIV = 11
+    RT_OPT_SCHED_QUORUM_MIN = 10, RT_OPT_SCHED_QUORUM_DIV = 11,
+    /* Pipeline 2: number of suspend / walk / resume rounds before the remaining paths are
+     * finished with in-place walks (default 5; 0 = in-place walks only), and the number of
+     * free lanes at which a walking wave fetches new rays (default 16). */
+    RT_OPT_WF_ROUNDS = 12, RT_OPT_WF_REFILL = 13
 };
 
 /* ---- device context ------------------------------------------------------ */

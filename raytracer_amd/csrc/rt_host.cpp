@@ -35,6 +35,12 @@ hipError_t rt_launch_schedkernel_strict(const DevScene*, const rt_push_constants
                                         DevCounters*, int, int, unsigned long long*, int, hipStream_t, unsigned long long*);
 hipError_t rt_launch_schedkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
                                       DevCounters*, int, int, unsigned long long*, int, hipStream_t, unsigned long long*);
+hipError_t rt_launch_wf_path_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, const DevWavefront*, void*, void*,
+                                    DevCounters*, int, int, int, int, int, hipStream_t);
+hipError_t rt_launch_wf_path_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, const DevWavefront*, void*, void*,
+                                  DevCounters*, int, int, int, int, int, hipStream_t);
+hipError_t rt_launch_wf_walk_strict(const DevScene*, const rt_push_constants*, const DevWavefront*, int, int, int, hipStream_t);
+hipError_t rt_launch_wf_walk_fast(const DevScene*, const rt_push_constants*, const DevWavefront*, int, int, int, hipStream_t);
 hipError_t rt_launch_resolve_strict(const void*, void*, size_t, float, hipStream_t);
 hipError_t rt_launch_resolve_fast(const void*, void*, size_t, float, hipStream_t);
 }
@@ -71,6 +77,12 @@ struct rt_ctx {
     int wavesPerCU = 12;
     int policy[5] = { 0, 0, 0, 4, 8 };   // biasObject, biasTrav, biasShade, quorumMin, quorumDiv
 
+    // wavefront pipeline: ray state and lists, sized for the current image
+    DevWavefront wf{};
+    void* wfMem = nullptr;
+    size_t wfSlots = 0;
+    int wfRounds = 5, wfRefill = 16;
+
     int optFast = 0, optPipeline = 0, tileRank = 0, tileWorld = 1, tileSize = 64;
     std::string error;
 };
@@ -105,6 +117,14 @@ void freeScene(rt_ctx* c)
     }
     c->haveScene = false;
     c->sceneBytes = 0;
+}
+
+void freeWavefront(rt_ctx* c)
+{
+    if (c->wfMem) (void)hipFree(c->wfMem);
+    c->wfMem = nullptr;
+    c->wfSlots = 0;
+    c->wf = DevWavefront{};
 }
 
 void freeImages(rt_ctx* c)
@@ -321,12 +341,66 @@ int checkRenderable(rt_ctx* ctx, const rt_push_constants* pc)
     return RT_OK;
 }
 
+// One allocation: control words, two job buffers, the result lists.
+int ensureWavefront(rt_ctx* ctx)
+{
+    const size_t slots = (size_t)ctx->width * (size_t)ctx->height;
+    if (ctx->wfMem && ctx->wfSlots == slots) return RT_OK;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    freeWavefront(ctx);
+    // a round's list holds at most one entry per pixel, plus one partly used block of 256 entries
+    // per resident wave and list
+    const size_t listCap = ((slots + (size_t)std::max(1, ctx->computeUnits) * 32 * 256 + 63) / 64) * 64;
+    if (slots == 0 || listCap > 0x7fffffffULL) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large for the wavefront pipeline");
+    const size_t ctlBytes = 4096;
+    static_assert((RT_WF_MAX_ROUNDS + 2) * RT_WF_WORDS_PER_ROUND * sizeof(uint32_t) <= 4096, "control block");
+    const size_t jobBytes = (size_t)RT_WF_JOB_ARRAYS * listCap * 16;
+    const size_t resBytes = (size_t)2 * RT_WF_RES_ARRAYS * listCap * 16;
+    RT_HIP(ctx, hipMalloc(&ctx->wfMem, ctlBytes + 2 * jobBytes + resBytes));
+    char* base = static_cast<char*>(ctx->wfMem);
+    ctx->wf.counts = reinterpret_cast<uint32_t*>(base);
+    ctx->wf.jobs[0] = base + ctlBytes;
+    ctx->wf.jobs[1] = base + ctlBytes + jobBytes;
+    ctx->wf.results = base + ctlBytes + 2 * jobBytes;
+    ctx->wf.listCap = (int32_t)listCap;
+    ctx->wfSlots = slots;
+    return RT_OK;
+}
+
+int launchWavefront(rt_ctx* ctx, const rt_push_constants& pc, const DevLaunch& L, bool statsOnly, bool countBuild)
+{
+    int rc = ensureWavefront(ctx);
+    if (rc != RT_OK) return rc;
+    DevWavefront W = ctx->wf;
+    W.refillMin = std::max(1, std::min(64, ctx->wfRefill));
+    const int rounds = std::max(0, std::min(RT_WF_MAX_ROUNDS, ctx->wfRounds));
+    RT_HIP(ctx, hipMemsetAsync(W.counts, 0, 4096, ctx->stream));
+    auto path = ctx->optFast ? rt_launch_wf_path_fast : rt_launch_wf_path_strict;
+    auto walk = ctx->optFast ? rt_launch_wf_walk_fast : rt_launch_wf_walk_strict;
+    const long long tileWaves = (long long)L.ownedTiles * (L.tileSize / 8) * (L.tileSize / 8);
+    if (tileWaves > 0x7fffffffLL) return fail(ctx, RT_ERR_UNSUPPORTED, "too many tiles");
+    const int resident = std::max(1, ctx->computeUnits) * ctx->wavesPerCU;
+    DevCounters* cnt = statsOnly ? ctx->dCounters : nullptr;
+    hipError_t e = path(&ctx->scene, &pc, &L, &W, ctx->accum, ctx->draw, cnt, countBuild ? 1 : 0, statsOnly ? 1 : 0, 0,
+                        rounds == 0 ? 1 : 0, (int)std::min<long long>(tileWaves, resident), ctx->stream);
+    for (int r = 0; r < rounds && e == hipSuccess; ++r) {
+        e = walk(&ctx->scene, &pc, &W, countBuild ? 1 : 0, r, resident, ctx->stream);
+        if (e != hipSuccess) break;
+        e = path(&ctx->scene, &pc, &L, &W, ctx->accum, ctx->draw, cnt, countBuild ? 1 : 0, statsOnly ? 1 : 0, r + 1,
+                 r + 1 == rounds ? 1 : 0, resident, ctx->stream);
+    }
+    if (e != hipSuccess) return failHip(ctx, e, "kernel launch");
+    return RT_OK;
+}
+
 int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsigned long long* diag = nullptr)
 {
     const DevLaunch L = makeLaunch(ctx);
     const bool countBuild = statsOnly || pc.renderMode == 3 || pc.renderMode == 4;
     const bool pathTrace = pc.renderMode == 0 || pc.renderMode == 3 || pc.renderMode == 4;
     hipError_t e;
+    if (ctx->optPipeline == 2 && pathTrace && pc.raysPerPixel >= 1 && ctx->scene.objectCount < 65535)   // object indices are packed in 16 bits
+        return launchWavefront(ctx, pc, L, statsOnly, countBuild);
     if (ctx->optPipeline == 1 && pathTrace && pc.raysPerPixel >= 1) {
         // persistent grid: enough 64-lane blocks to fill every CU; lanes pull pixels from a counter
         const long long wavesNeeded = ((long long)L.ownedTiles * L.tileSize * L.tileSize + 63) / 64;
@@ -385,6 +459,7 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     freeScene(c);
     freeImages(c);
+    freeWavefront(c);
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->dQueue) (void)hipFree(c->dQueue);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -409,7 +484,7 @@ int rt_set_option(rt_ctx* ctx, int option, int value)
     switch (option) {
     case RT_OPT_FAST_MATH: ctx->optFast = value ? 1 : 0; return RT_OK;
     case RT_OPT_PIPELINE:
-        if (value < 0 || value > 1) return fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step) or 1 (wave-scheduled)");
+        if (value < 0 || value > 2) return fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step), 1 (wave-scheduled) or 2 (wavefront)");
         ctx->optPipeline = value;
         return RT_OK;
     case RT_OPT_WAVES_PER_CU:
@@ -420,6 +495,14 @@ int rt_set_option(rt_ctx* ctx, int option, int value)
     case RT_OPT_SCHED_QUORUM_MIN: case RT_OPT_SCHED_QUORUM_DIV:
         if (value < -64 || value > 64) return fail(ctx, RT_ERR_INVALID_ARG, "scheduling parameter out of range");
         ctx->policy[option - RT_OPT_SCHED_BIAS_OBJECT] = value;
+        return RT_OK;
+    case RT_OPT_WF_ROUNDS:
+        if (value < 0 || value > RT_WF_MAX_ROUNDS) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront rounds must be in [0,30]");
+        ctx->wfRounds = value;
+        return RT_OK;
+    case RT_OPT_WF_REFILL:
+        if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront refill threshold must be in [1,64]");
+        ctx->wfRefill = value;
         return RT_OK;
     case RT_OPT_TILE_RANK:
         if (value < 0) return fail(ctx, RT_ERR_INVALID_ARG, "tile rank must be >= 0");
@@ -444,6 +527,8 @@ int rt_get_option(rt_ctx* ctx, int option, int* value)
     case RT_OPT_FAST_MATH: *value = ctx->optFast; return RT_OK;
     case RT_OPT_PIPELINE: *value = ctx->optPipeline; return RT_OK;
     case RT_OPT_WAVES_PER_CU: *value = ctx->wavesPerCU; return RT_OK;
+    case RT_OPT_WF_ROUNDS: *value = ctx->wfRounds; return RT_OK;
+    case RT_OPT_WF_REFILL: *value = ctx->wfRefill; return RT_OK;
     case RT_OPT_TILE_RANK: *value = ctx->tileRank; return RT_OK;
     case RT_OPT_TILE_WORLD: *value = ctx->tileWorld; return RT_OK;
     case RT_OPT_TILE_SIZE: *value = ctx->tileSize; return RT_OK;

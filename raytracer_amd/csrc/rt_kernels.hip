@@ -1116,6 +1116,723 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Wavefront pipeline: the path loop and the BVH walks run in different kernels.
+//
+// In the lock-step kernel two thirds of the issue slots go to BVH walks whose lengths differ
+// wildly between the 64 rays of a wave. Here a ray that enters the box of a BVH parent leaves the
+// path kernel as a job (DevWavefront), and so does every ray that has just been started:
+//   rt_wf_path   round 0: one lane per pixel - camera ray and the first part of GetHit's object
+//                loop (parent boxes, leaf parents such as the six walls) up to the first BVH
+//                parent the ray enters;
+//                round r > 0: takes the rays whose walk has finished and runs, for 64 of them in
+//                step, the rest of the object loop, shading, the shadow ray and the start of the
+//                next ray (regular and shadow rays come in separate lists so that a wave stays in
+//                step);
+//                last round: BVH parents are walked in place, so nothing is left over.
+//   rt_wf_walk   walks the BVH parent a job has entered and the BVH parents that follow it in the
+//                object loop. Every lane runs its own small state machine (one parent box / one
+//                two-child record / one triangle per step) and takes the next job from the list
+//                when it is done, so the wave stays full whatever the lengths of the walks.
+// Kernel boundaries on one stream order the hand-over of jobs and results; within a kernel only
+// atomic counters are shared. Per ray the arithmetic and its order are those of the lock-step
+// kernel, so the images are the same bit for bit.
+
+// Walk of one BVH parent for one ray (raytrace.comp:523-606) with the lock-step kernel's loop.
+// Returns true when `early` is set and a hit was accepted.
+template <bool COUNT>
+__device__ __forceinline__ bool walk_in_place(const DevScene& S, const DevObject* ob, int objIndex, bool early, V3 org, V3 dirN,
+                                              float tMin, Best& best, Counters& cnt, uint2* stack)
+{
+    V3 lo = xform(ob->inv, org, 1.0f);
+    V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
+    V3 linv;
+    const bool parL = lean_inverse(ld, linv);
+    int cur = ob->root;
+    int sp = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            float4 a = np[0], b = np[1], c = np[2];
+            int2 refs = *reinterpret_cast<const int2*>(np + 3);
+            float EF, ES;
+            bool okF, okS;
+            if (__any(parL)) {
+                okF = lean_box<true>(lo, linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
+                okS = lean_box<true>(lo, linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
+            } else {
+                okF = lean_box<false>(lo, linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
+                okS = lean_box<false>(lo, linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
+            }
+            if (COUNT) cnt.nodeTests += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
+            const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (best.closest > EF);
+            const bool canS = refs.y > RT_REF_LIVE_MIN && okS;
+            if (goF) {
+                if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(ES)); ++sp; }
+                cur = refs.x;
+                continue;
+            }
+            if (canS && (best.closest > ES)) { cur = refs.y; continue; }
+        } else {
+            int k = ~cur;
+            for (;;) {
+                const float4* tp = reinterpret_cast<const float4*>(S.tris + k);
+                float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                const int remaining = __float_as_int(t0.w);
+                if (COUNT) cnt.triTests++;
+                V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
+                V3 h = cross3(ld, e2);
+                float det = dot3(e1, h);
+                const float eps = 1e-5f;
+                if (!(fabsf(det) < eps)) {
+                    float invDet = 1.0f / det;
+                    V3 s = lo - v0;
+                    float u = invDet * dot3(s, h);
+                    V3 sc = cross3(s, e1);
+                    float v = invDet * dot3(ld, sc);
+                    bool miss = (u < -eps || u > 1.0f + eps) || (v < -eps || u + v > 1.0f + eps);
+                    float hitT = invDet * dot3(e2, sc);
+                    if (!miss && (hitT >= tMin && hitT <= best.closest) && hitT > eps) {
+                        V3 p = lo + ld * hitT;
+                        V3 wp = xform(ob->fwd, p, 1.0f);
+                        float worldT = dot3(wp - org, dirN);
+                        if (worldT > tMin && worldT < best.closest) {
+                            best.closest = worldT;
+                            best.tLocal = hitT;
+                            best.u = u; best.v = v;
+                            best.object = objIndex;
+                            best.tri = __float_as_int(t1.w);
+                            if (early) return true;
+                        }
+                    }
+                }
+                if (remaining <= 1) break;
+                ++k;
+            }
+        }
+        cur = RT_NONE;
+        while (sp > 0) {
+            --sp;
+            uint2 e = stack[sp * 64];
+            if (best.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+        }
+        if (cur == RT_NONE) return false;
+    }
+}
+
+// GetHit's object loop (raytrace.comp:458-520) up to the first BVH parent a lane enters: that lane
+// stops there (returned object index, -1 otherwise) with `best` as it is at that point. fresh =
+// false continues a GetHit call at object `next` with the `best` passed in (a ray back from a
+// walk). `anyhit` is wave-uniform. Leaf parents are tested in place.
+// INLINE: nobody stops; BVH parents are walked in place.
+template <bool COUNT, bool INLINE>
+__device__ __forceinline__ int trace_until_walk(const DevScene& S, int parentCount, bool anyhit, bool fresh, int next, V3 org,
+                                                V3 dirN, float tMin, Best& best, Counters& cnt, uint2* stack)
+{
+    const bool early = anyhit && !COUNT;
+    const bool permute = early && parentCount == S.objectCount;
+    if (fresh) {
+        best.closest = 1e20f;
+        best.object = -1;
+        best.tri = 0; best.u = 0.0f; best.v = 0.0f; best.tLocal = 0.0f;
+        if (COUNT) cnt.rays++;
+        next = permute ? S.anyFirst : 0;
+    }
+    V3 winv;
+    const bool parW = lean_inverse(dirN, winv);
+    int suspended = -1;
+    for (int pos = 0; pos < parentCount; ++pos) {
+        const int i = permute ? S.anyOrder[pos] : pos;
+        const DevObject* ob = S.objects + i;   // wave-uniform address
+        const int root = ob->root;
+        const int after = permute ? S.nextAny[i] : i + 1;
+        if (next != i) continue;
+        next = after;
+        if (COUNT) cnt.nodeTests++;
+        V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+        float E;
+        bool ok = (__any(parW) ? lean_box<true>(org, winv, bmn, bmx, tMin, E) : lean_box<false>(org, winv, bmn, bmx, tMin, E)) &&
+                  (best.closest > E);
+        if (ok) ok = !(distance_to_aabb(org, bmn, bmx) > best.closest);
+        if (!ok || !(root > RT_REF_LIVE_MIN)) continue;
+        if (root >= 0) {
+            if (INLINE) { if (walk_in_place<COUNT>(S, ob, i, early, org, dirN, tMin, best, cnt, stack)) next = parentCount; }
+            else { suspended = i; next = parentCount; }
+            continue;
+        }
+        V3 lo = xform(ob->inv, org, 1.0f);
+        V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
+        int k = ~root;
+        for (;;) {
+            const float4* tp = reinterpret_cast<const float4*>(S.tris + k);
+            float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            const int remaining = __float_as_int(t0.w);
+            if (COUNT) cnt.triTests++;
+            V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
+            V3 h = cross3(ld, e2);
+            float det = dot3(e1, h);
+            const float eps = 1e-5f;
+            if (!(fabsf(det) < eps)) {
+                float invDet = 1.0f / det;
+                V3 s = lo - v0;
+                float u = invDet * dot3(s, h);
+                V3 sc = cross3(s, e1);
+                float v = invDet * dot3(ld, sc);
+                bool miss = (u < -eps || u > 1.0f + eps) || (v < -eps || u + v > 1.0f + eps);
+                float hitT = invDet * dot3(e2, sc);
+                if (!miss && (hitT >= tMin && hitT <= best.closest) && hitT > eps) {
+                    V3 p = lo + ld * hitT;
+                    V3 wp = xform(ob->fwd, p, 1.0f);
+                    float worldT = dot3(wp - org, dirN);
+                    if (worldT > tMin && worldT < best.closest) {
+                        best.closest = worldT;
+                        best.tLocal = hitT;
+                        best.u = u; best.v = v;
+                        best.object = i;
+                        best.tri = __float_as_int(t1.w);
+                        if (early) { next = parentCount; break; }
+                    }
+                }
+            }
+            if (remaining <= 1) break;
+            ++k;
+        }
+    }
+    return suspended;
+}
+
+// List space is handed out to a wave in blocks of RT_WF_BLOCK entries (one atomic per block; one
+// per entry or per wave instruction would make the counter the bottleneck). A wave fills its
+// block in order; what it leaves unused is marked as a hole, which the readers skip.
+#define RT_WF_BLOCK 256
+struct WaveBlock { unsigned base, left; };   // wave-uniform
+
+// Index for each lane of `mask` (other lanes get an unspecified value). Whole wave.
+// `holes` is the array whose record marks an entry unused, `hole` that record.
+__device__ __forceinline__ unsigned wf_append(WaveBlock& blk, uint32_t* counter, float4* holes, float4 hole, unsigned long long mask)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned n = (unsigned)__popcll(mask);
+    if (n > blk.left) {
+        for (unsigned i = (unsigned)lane; i < blk.left; i += 64u) holes[blk.base + i] = hole;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(counter, (unsigned)RT_WF_BLOCK);
+        blk.base = (unsigned)__shfl((int)base, 0, 64);
+        blk.left = RT_WF_BLOCK;
+    }
+    const unsigned idx = blk.base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    blk.base += n;
+    blk.left -= n;
+    return idx;
+}
+__device__ __forceinline__ void wf_close(WaveBlock& blk, float4* holes, float4 hole)
+{
+    const int lane = threadIdx.x & 63;
+    for (unsigned i = (unsigned)lane; i < blk.left; i += 64u) holes[blk.base + i] = hole;
+    blk.left = 0;
+}
+
+__device__ __forceinline__ float4* wf_job(const DevWavefront& W, int parity, int part)
+{
+    return reinterpret_cast<float4*>(W.jobs[parity]) + (size_t)part * (size_t)W.listCap;
+}
+__device__ __forceinline__ float4* wf_res(const DevWavefront& W, int kind, int part)
+{
+    return reinterpret_cast<float4*>(W.results) + (size_t)(kind * RT_WF_RES_ARRAYS + part) * (size_t)W.listCap;
+}
+__device__ __forceinline__ float4 wf_job_hole() { return make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); }
+__device__ __forceinline__ float4 wf_res_hole() { return make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f); }
+
+struct PathVars {
+    V3 rayO, rayD;
+    V3 result, throughput;
+    int bounce, sample;
+    V3 nc;
+    V3 pendD, pendO, pendDir;
+};
+
+// The lanes with `emit` leave the path kernel: each becomes a job of this round. obj is the BVH
+// parent whose box the ray entered, or parentCount when its GetHit call is already complete.
+// Must be called by the whole wave.
+__device__ __forceinline__ void wf_emit(const DevWavefront& W, int round, WaveBlock& blk, bool emit, int slot, bool shadow, int obj,
+                                        V3 org, V3 dir, const Best& best, const PathVars& v, const Counters& cnt, bool wide)
+{
+    const unsigned long long m = __ballot(emit);
+    if (m == 0) return;
+    const int par = round & 1;
+    const unsigned idx = wf_append(blk, &W.counts[round * RT_WF_WORDS_PER_ROUND + 0], wf_job(W, par, 0), wf_job_hole(), m);
+    if (emit) {
+        const uint32_t meta = (uint32_t)obj | (shadow ? 0x80000000u : 0u);
+        wf_job(W, par, 0)[idx] = make_float4(org.x, org.y, org.z, __int_as_float(slot));
+        wf_job(W, par, 1)[idx] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(meta));
+        wf_job(W, par, 2)[idx] = make_float4(best.closest, best.tLocal, best.u, best.v);
+        wf_job(W, par, 3)[idx] = make_float4(__int_as_float(best.object + 1), __int_as_float(best.tri),
+                                             __int_as_float(cnt.nodeTests), __int_as_float(cnt.triTests));
+        wf_job(W, par, 4)[idx] = make_float4(v.throughput.x, v.throughput.y, v.throughput.z, __int_as_float(v.sample));
+        wf_job(W, par, 5)[idx] = make_float4(v.result.x, v.result.y, v.result.z, __int_as_float(v.bounce));
+        if (shadow) {
+            wf_job(W, par, 6)[idx] = make_float4(v.pendD.x, v.pendD.y, v.pendD.z, 0.0f);
+            wf_job(W, par, 7)[idx] = make_float4(v.pendO.x, v.pendO.y, v.pendO.z, 0.0f);
+            wf_job(W, par, 8)[idx] = make_float4(v.pendDir.x, v.pendDir.y, v.pendDir.z, 0.0f);
+        }
+        if (wide) wf_job(W, par, 9)[idx] = make_float4(v.nc.x, v.nc.y, v.nc.z, __int_as_float(cnt.rays));
+    }
+}
+
+// Persistent grid. Round 0 takes 8x8 pixel tiles, round > 0 chunks of 64 results of the previous
+// round's walks, from a counter. One pass over a chunk is: the rest of the GetHit call the ray
+// came back from, shading, the shadow ray, the first part of the next ray's GetHit call - then
+// every lane that still has a path leaves as a job of this round, so a pass is never continued
+// for a few lanes only. INLINE (the last round): BVH parents are walked in place and the paths
+// run to their end (needs the traversal stack in LDS).
+template <bool COUNT, bool INLINE>
+__global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_constants pc, DevLaunch L, DevWavefront W,
+                                                        float4* __restrict__ accum, float4* __restrict__ out,
+                                                        DevCounters* counters, int statsOnly, int round)
+{
+    extern __shared__ uint2 stackMem[];
+    const int lane = threadIdx.x;
+    uint2* stack = stackMem + lane;
+    const int bounces = pc.maxBounces + 1;
+    const int parentCount = pc.parentBVHCount;
+    const int rpp = pc.raysPerPixel;
+    const int mode = pc.renderMode;
+    const float tMin = 0.001f;
+    const bool wide = COUNT || rpp > 1;
+    const int prev = (round + 1) & 1;   // parity of the previous round's job buffer
+    const bool leadingBvh = parentCount > 0 && S.objects[0].root >= 0;
+    long long totRays = 0, totNode = 0, totTri = 0, totSamples = 0;
+
+    WaveBlock blk;
+    blk.base = 0; blk.left = 0;
+    unsigned grabNext = 0, grabLeft = 0;
+    unsigned nReg = 0, nShd = 0, chunksReg = 0, chunks = 0;
+    uint32_t* workCounter;
+    if (round > 0) {
+        nReg = W.counts[(round - 1) * RT_WF_WORDS_PER_ROUND + 2];
+        nShd = W.counts[(round - 1) * RT_WF_WORDS_PER_ROUND + 3];
+        chunksReg = (nReg + 63u) >> 6;
+        chunks = chunksReg + ((nShd + 63u) >> 6);
+        workCounter = &W.counts[(round - 1) * RT_WF_WORDS_PER_ROUND + 4];
+    } else {
+        const int wavesX = L.tileSize >> 3;
+        chunks = (unsigned)(L.ownedTiles * wavesX * wavesX);
+        workCounter = &W.counts[(RT_WF_MAX_ROUNDS + 1) * RT_WF_WORDS_PER_ROUND];
+    }
+
+    for (;;) {
+        // ---- lanes of this pass: a pixel tile (round 0) or 64 results ----
+        // (chunks are taken four at a time: atomics on one address are served one by one)
+        if (grabLeft == 0) {
+            unsigned g = 0;
+            if (lane == 0) g = atomicAdd(workCounter, 4u);
+            grabNext = (unsigned)__shfl((int)g, 0, 64);
+            grabLeft = 4;
+        }
+        const unsigned chunk = grabNext;
+        ++grabNext; --grabLeft;
+        if (chunk >= chunks) break;
+
+        int entry = 0;          // 0 new path, 1 back from a regular ray's walk, 2 back from a shadow ray's walk
+        bool alive = false;
+        int slot = 0, px = 0, py = 0;
+        int resumeObj = 0;                       // object at which a resumed GetHit call continues
+        V3 resumeO = mk(0.0f, 0.0f, 0.0f);       // origin of a resumed shadow ray
+        uint32_t seed = 0;
+        PathVars v;
+        Counters cnt;
+        Best best;
+        cnt.rays = cnt.nodeTests = cnt.triTests = 0;
+        v.nc = mk(0.0f, 0.0f, 0.0f);
+        v.result = mk(0.0f, 0.0f, 0.0f); v.throughput = mk(1.0f, 1.0f, 1.0f);
+        v.pendD = v.pendO = v.pendDir = mk(0.0f, 0.0f, 0.0f);
+        v.rayO = mk(0.0f, 0.0f, 0.0f); v.rayD = mk(0.0f, 0.0f, 1.0f);
+        v.bounce = 0; v.sample = 0;
+        best.closest = 1e20f; best.tLocal = 0.0f; best.u = 0.0f; best.v = 0.0f; best.object = -1; best.tri = 0;
+        if (round == 0) {
+            const int wavesX = L.tileSize >> 3;
+            const int wavesPerTile = wavesX * wavesX;
+            const int ownedTile = (int)chunk / wavesPerTile;
+            const int sub = (int)chunk - ownedTile * wavesPerTile;
+            const int tile = L.tileRank + ownedTile * L.tileWorld;
+            const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
+            const int sy = sub / wavesX, sx = sub - sy * wavesX;
+            px = tx * L.tileSize + sx * 8 + (lane & 7);
+            py = ty * L.tileSize + sy * 8 + (lane >> 3);
+            alive = px < L.width && py < L.height && rpp >= 1;
+            slot = py * L.width + px;
+            if (alive) {
+                seed = seed_from_coords((uint32_t)px, (uint32_t)py, (uint32_t)pc.frame, 0u);
+                Ray r0 = get_ray(pc, px, py, seed);
+                v.rayO = r0.o; v.rayD = r0.d;
+            }
+        } else {
+            const int kind = chunk >= chunksReg ? 1 : 0;
+            const unsigned i = (kind ? chunk - chunksReg : chunk) * 64u + (unsigned)lane;
+            entry = kind + 1;
+            int job = -1;
+            float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0;
+            if (i < (kind ? nShd : nReg)) {
+                r0 = wf_res(W, kind, 0)[i];
+                r1 = wf_res(W, kind, 1)[i];
+                job = __float_as_int(r1.z);
+            }
+            alive = job >= 0;
+            if (alive) {
+                float4 a = wf_job(W, prev, 0)[job], e = wf_job(W, prev, 4)[job], f = wf_job(W, prev, 5)[job];
+                slot = __float_as_int(a.w);
+                py = slot / L.width; px = slot - py * L.width;
+                best.closest = r0.x; best.tLocal = r0.y; best.u = r0.z; best.v = r0.w;
+                best.object = (__float_as_int(r1.x) & 0xffff) - 1; best.tri = __float_as_int(r1.y);
+                resumeObj = (int)((unsigned)__float_as_int(r1.x) >> 16);
+                if (COUNT) { cnt.nodeTests = __float_as_int(r1.w); cnt.triTests = __float_as_int(wf_res(W, kind, 2)[i].x); }
+                v.throughput = mk(e.x, e.y, e.z); v.sample = __float_as_int(e.w);
+                v.result = mk(f.x, f.y, f.z); v.bounce = __float_as_int(f.w);
+                seed = seed_from_coords((uint32_t)px, (uint32_t)py, (uint32_t)pc.frame, (uint32_t)v.sample);
+                if (kind) {
+                    float4 g = wf_job(W, prev, 6)[job], h = wf_job(W, prev, 7)[job], k = wf_job(W, prev, 8)[job];
+                    v.pendD = mk(g.x, g.y, g.z); v.pendO = mk(h.x, h.y, h.z); v.pendDir = mk(k.x, k.y, k.z);
+                    resumeO = mk(a.x, a.y, a.z);
+                } else {
+                    float4 b = wf_job(W, prev, 1)[job];
+                    v.rayO = mk(a.x, a.y, a.z); v.rayD = mk(b.x, b.y, b.z);
+                }
+                if (wide) {
+                    float4 j = wf_job(W, prev, 9)[job];
+                    v.nc = mk(j.x, j.y, j.z); cnt.rays = __float_as_int(j.w);
+                }
+            }
+        }
+
+        // ---- the path loop: RayColour (raytrace.comp:692-769) inside Pathtrace's sample loop ----
+        bool firstPass = true;
+        while (__any(alive)) {
+            bool pathEnd = false, needShadow = false;
+            V3 so = v.rayO;
+            const V3 negSun = -ld3(pc.sunDirection);
+            if (!(firstPass && entry == 2)) {
+                V3 dirN = normalize3(v.rayD);
+                {
+                    const bool fresh = !(firstPass && entry == 1);
+                    if (!INLINE && fresh && leadingBvh) {
+                        // a ray that has just started, in a scene whose first parent is a BVH parent:
+                        // the walk kernel starts its GetHit call, box test of that parent included
+                        best.closest = 1e20f; best.object = -1; best.tri = 0; best.u = 0.0f; best.v = 0.0f; best.tLocal = 0.0f;
+                        if (COUNT && alive) cnt.rays++;
+                        wf_emit(W, round, blk, alive, slot, false, 0x40000000, v.rayO, v.rayD, best, v, cnt, wide);
+                        alive = false;
+                    } else {
+                        int obj = -1;
+                        if (alive)
+                            obj = trace_until_walk<COUNT, INLINE>(S, parentCount, false, fresh, resumeObj, v.rayO, dirN, tMin, best, cnt, stack);
+                        if (!INLINE) {
+                            // a ray that has just started leaves in any case; one that came back from a
+                            // walk leaves only if it enters another BVH parent
+                            const bool emit = alive && (fresh || obj >= 0);
+                            wf_emit(W, round, blk, emit, slot, false, obj >= 0 ? obj : parentCount, v.rayO, v.rayD, best, v, cnt, wide);
+                            if (emit) alive = false;
+                        }
+                    }
+                }
+                if (alive) {
+                    HitRec rec;
+                    finish_hit(S, v.rayO, dirN, best, rec);
+                    if (!rec.hit) {
+                        v.result = v.result + v.throughput * environment_colour(pc, v.rayD);
+                        pathEnd = true;
+                    } else if (!rec.frontFace) {
+                        pathEnd = true;
+                    } else {
+                        DevMaterial m = load_material(S, rec.matIndex);
+                        V3 emitted = ld3(m.colour) * m.emission;
+                        v.result = v.result + v.throughput * emitted;
+                        if (m.emission > 0.0f) {
+                            pathEnd = true;
+                        } else {
+                            float nDotL = gmax(dot3(rec.normal, negSun), 0.0f);
+                            V3 attenuation;
+                            Ray scattered;
+                            material_scatter(m, v.rayD, rec, seed, attenuation, scattered);
+                            if (nDotL > 0.0f) {
+                                V3 sun = ld3(pc.sunColour) * pc.sunIntensity;
+                                const float INV_PI = 0.31830988618f;
+                                V3 direct = sun * (nDotL * INV_PI);
+                                if (m.refractionIndex == 0.0f) v.pendD = (v.throughput * ld3(m.colour)) * direct;
+                                else v.pendD = (v.throughput * reflectance(nDotL, m.refractionIndex)) * direct;
+                                so = rec.point + rec.normal * 0.01f;
+                                needShadow = true;
+                            }
+                            v.pendO = scattered.o; v.pendDir = scattered.d;
+                            v.throughput = v.throughput * attenuation;
+                        }
+                    }
+                }
+            } else {
+                needShadow = alive;   // back from the walk of a shadow ray
+            }
+            // ShadowTransmission, raytrace.comp:612-621,733-753
+            if (__any(needShadow)) {
+                const bool fresh = !(firstPass && entry == 2);
+                if (!fresh) so = resumeO;
+                int obj = -1;
+                if (needShadow)
+                    obj = trace_until_walk<COUNT, INLINE>(S, parentCount, true, fresh, resumeObj, so, normalize3(negSun), tMin, best, cnt, stack);
+                if (!INLINE) {
+                    const bool emit = needShadow && obj >= 0;
+                    wf_emit(W, round, blk, emit, slot, true, obj, so, negSun, best, v, cnt, wide);
+                    if (emit) { alive = false; needShadow = false; }
+                }
+                if (needShadow && best.object < 0) v.result = v.result + v.pendD;
+            }
+            if (alive && !pathEnd) {
+                // the scattered ray is the next ray of the path
+                v.rayO = v.pendO; v.rayD = v.pendDir;
+                ++v.bounce;
+                if (v.bounce >= bounces) pathEnd = true;
+            }
+            if (alive && pathEnd) {
+                // end of one RayColour call, raytrace.comp:784
+                v.nc = v.nc + v.result;
+                ++v.sample;
+                if (v.sample < rpp) {
+                    seed = seed_from_coords((uint32_t)px, (uint32_t)py, (uint32_t)pc.frame, (uint32_t)v.sample);
+                    Ray r0 = get_ray(pc, px, py, seed);
+                    v.rayO = r0.o; v.rayD = r0.d;
+                    v.result = mk(0.0f, 0.0f, 0.0f);
+                    v.throughput = mk(1.0f, 1.0f, 1.0f);
+                    v.bounce = 0;
+                } else {
+                    // rest of Pathtrace, raytrace.comp:787-816
+                    const size_t idx = (size_t)py * (size_t)L.width + (size_t)px;
+                    if (!statsOnly) {
+                        if (mode == 0) {
+                            float raysPerPixelRatio = 1.0f / (float)rpp;
+                            float accumulationMultiplier = pc.accumulateFrames == 1 ? 1.0f / (float)(pc.frame + 1) : 1.0f;
+                            float4 acc = accum[idx];
+                            V3 ncs = v.nc * raysPerPixelRatio;
+                            acc.x += ncs.x; acc.y += ncs.y; acc.z += ncs.z;
+                            accum[idx] = acc;
+                            float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(ncs.x, ncs.y, ncs.z, 1.0f);
+                            avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
+                            out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
+                        } else {
+                            int threshold = mode == 3 ? pc.triangleTestThreshold : pc.bvhNodeTestThreshold;
+                            int target = mode == 3 ? cnt.triTests : cnt.nodeTests;
+                            int grey = (int)((float)target / (float)threshold * 255.0f);
+                            grey = grey < 0 ? 0 : (grey > 255 ? 255 : grey);
+                            float g = (float)grey / 255.0f;
+                            float4 c = make_float4(g, g, g, 1.0f);
+                            if (cnt.triTests > threshold) c = make_float4(1.0f, 0.0f, 0.0f, 1.0f);
+                            out[idx] = c;
+                        }
+                    }
+                    if (COUNT) { totRays += cnt.rays; totNode += cnt.nodeTests; totTri += cnt.triTests; totSamples += v.sample; }
+                    alive = false;
+                }
+            }
+            firstPass = false;
+        }
+    }
+    if (!INLINE) wf_close(blk, wf_job(W, round & 1, 0), wf_job_hole());
+
+    if (COUNT && counters != nullptr) {
+        for (int off = 32; off > 0; off >>= 1) {
+            totRays += __shfl_down(totRays, off, 64);
+            totNode += __shfl_down(totNode, off, 64);
+            totTri += __shfl_down(totTri, off, 64);
+            totSamples += __shfl_down(totSamples, off, 64);
+        }
+        if (lane == 0 && (totRays | totNode | totTri | totSamples) != 0) {
+            atomicAdd(&counters->rays, (unsigned long long)totRays);
+            atomicAdd(&counters->nodeTests, (unsigned long long)totNode);
+            atomicAdd(&counters->triTests, (unsigned long long)totTri);
+            atomicAdd(&counters->samples, (unsigned long long)totSamples);
+        }
+    }
+}
+
+#define RT_WF_BOX 0x7ffffffd   /* LaneTrace::cur: at the parent box of object `obj` */
+
+// Persistent grid. Lane states: 0 free, 1 walking, 2 finished (result still in registers), 3 retired.
+template <bool COUNT>
+__global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_constants pc, DevWavefront W, int round)
+{
+    extern __shared__ uint2 stackMem[];
+    const int lane = threadIdx.x;
+    uint2* stack = stackMem + lane;
+    const int parentCount = pc.parentBVHCount;
+    const float tMin = 0.001f;
+    const bool permute = !COUNT && parentCount == S.objectCount;
+    const int par = round & 1;
+    uint32_t* ctl = W.counts + round * RT_WF_WORDS_PER_ROUND;
+    const unsigned jobs = ctl[0];
+    const int refillMin = W.refillMin;
+
+    int st = 0, job = 0, flags = 0;
+    int cNode = 0, cTri = 0;
+    V3 winv = mk(1.0f, 1.0f, 1.0f);
+    LaneTrace t;
+    t.rayO = mk(0.0f, 0.0f, 0.0f); t.dirN = mk(0.0f, 0.0f, 1.0f); t.lo = t.rayO; t.ld = t.dirN; t.linv = winv;
+    t.closest = 1e20f; t.bestT = t.bestU = t.bestV = 0.0f; t.bestObj = -1; t.bestTri = 0;
+    t.obj = 0; t.cur = RT_WF_BOX; t.sp = 0;
+    bool exhausted = false;   // wave-uniform: the list has no more entries
+    WaveBlock outReg, outShd;   // this wave's blocks in the two result lists
+    outReg.base = outReg.left = outShd.base = outShd.left = 0;
+    unsigned inNext = 0, inLeft = 0;   // this wave's range of the job list
+
+    for (;;) {
+        const int walking = __popcll(__ballot(st == 1));
+        if (walking == 0 || (!exhausted && walking <= 64 - refillMin)) {
+            // hand finished rays on: a result record in the list of the ray's kind
+            const bool fin = st == 2;
+            const unsigned long long mReg = __ballot(fin && !(flags & F_SHADOW));
+            const unsigned long long mShd = __ballot(fin && (flags & F_SHADOW));
+            unsigned iReg = 0, iShd = 0;
+            if (mReg) iReg = wf_append(outReg, &ctl[2], wf_res(W, 0, 1), wf_res_hole(), mReg);
+            if (mShd) iShd = wf_append(outShd, &ctl[3], wf_res(W, 1, 1), wf_res_hole(), mShd);
+            if (fin) {
+                const int kind = (flags & F_SHADOW) ? 1 : 0;
+                const unsigned i = kind ? iShd : iReg;
+                wf_res(W, kind, 0)[i] = make_float4(t.closest, t.bestT, t.bestU, t.bestV);
+                wf_res(W, kind, 1)[i] = make_float4(__int_as_float((t.bestObj + 1) | (t.obj << 16)), __int_as_float(t.bestTri),
+                                                    __int_as_float(job), __int_as_float(cNode));
+                if (COUNT) wf_res(W, kind, 2)[i] = make_float4(__int_as_float(cTri), 0.0f, 0.0f, 0.0f);
+                st = 0;
+            }
+            // take new jobs from the list, of which this wave reserves 256 entries at a time
+            if (!exhausted) {
+                const unsigned long long need = __ballot(st == 0);
+                const unsigned n = (unsigned)__popcll(need);
+                const unsigned rank = (unsigned)__popcll(need & ((1ull << lane) - 1ull));
+                unsigned fresh = 0;
+                if (n > inLeft) {
+                    if (lane == 0) fresh = atomicAdd(&ctl[1], 256u);
+                    fresh = (unsigned)__shfl((int)fresh, 0, 64);
+                }
+                const unsigned idx = rank < inLeft ? inNext + rank : fresh + (rank - inLeft);
+                if (n > inLeft) { inNext = fresh + (n - inLeft); inLeft = 256u - (n - inLeft); }
+                else { inNext += n; inLeft -= n; }
+                if (st == 0 && idx >= jobs) st = 3;
+                exhausted = __any(st == 3);
+                if (st == 0) {
+                    float4 a = wf_job(W, par, 0)[idx], b = wf_job(W, par, 1)[idx];
+                    if (__float_as_int(a.w) >= 0) {   // else an unused entry of a writer's block
+                        float4 c = wf_job(W, par, 2)[idx], d = wf_job(W, par, 3)[idx];
+                        const uint32_t meta = __float_as_uint(b.w);
+                        job = (int)idx;
+                        t.rayO = mk(a.x, a.y, a.z);
+                        t.dirN = normalize3(mk(b.x, b.y, b.z));
+                        flags = (meta & 0x80000000u) ? F_SHADOW : 0;
+                        if (lean_inverse(t.dirN, winv)) flags |= F_PAR_WORLD;
+                        t.closest = c.x; t.bestT = c.y; t.bestU = c.z; t.bestV = c.w;
+                        t.bestObj = __float_as_int(d.x) - 1; t.bestTri = __float_as_int(d.y);
+                        cNode = __float_as_int(d.z); cTri = __float_as_int(d.w);
+                        t.obj = (int)(meta & 0x3fffffffu);
+                        st = 2;   // a GetHit call that was already complete passes straight through
+                        if (meta & 0x40000000u) {
+                            // a ray that has just started: begin with the box of parent 0
+                            t.obj = 0; t.cur = RT_WF_BOX; st = 1;
+                        } else if (t.obj < parentCount) {
+                            // the box of this object was entered by the path kernel: straight to its root
+                            const float4* op = reinterpret_cast<const float4*>(S.objects + t.obj);
+                            float4 b0 = op[0], i0 = op[2], i1 = op[3], i2 = op[4];
+                            t.lo = mk((i0.x * t.rayO.x + i0.y * t.rayO.y) + (i0.z * t.rayO.z + i0.w * 1.0f),
+                                      (i1.x * t.rayO.x + i1.y * t.rayO.y) + (i1.z * t.rayO.z + i1.w * 1.0f),
+                                      (i2.x * t.rayO.x + i2.y * t.rayO.y) + (i2.z * t.rayO.z + i2.w * 1.0f));
+                            t.ld = normalize3(mk((i0.x * t.dirN.x + i0.y * t.dirN.y) + (i0.z * t.dirN.z + i0.w * 0.0f),
+                                                 (i1.x * t.dirN.x + i1.y * t.dirN.y) + (i1.z * t.dirN.z + i1.w * 0.0f),
+                                                 (i2.x * t.dirN.x + i2.y * t.dirN.y) + (i2.z * t.dirN.z + i2.w * 0.0f)));
+                            flags = lean_inverse(t.ld, t.linv) ? (flags | F_PAR_LOCAL) : (flags & ~F_PAR_LOCAL);
+                            t.sp = 0;
+                            t.cur = __float_as_int(b0.w);
+                            st = 1;
+                        }
+                    }
+                }
+            }
+            if (!__any(st == 1)) {
+                if (exhausted && !__any(st == 2)) break;
+                continue;   // finished lanes are handed on, free lanes try the list again
+            }
+        }
+
+        if (st == 1) {
+            int next = t.cur;
+            if (t.cur == RT_WF_BOX) {
+                // next parent, raytrace.comp:458-486: a BVH parent is walked here, at anything else
+                // the ray goes back to the path kernel, which continues the object loop there
+                int root = -1;
+                float4 b0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const float4* op = reinterpret_cast<const float4*>(S.objects + (t.obj < parentCount ? t.obj : 0));
+                if (t.obj < parentCount) { b0 = op[0]; root = __float_as_int(b0.w); }
+                if (root < 0) {
+                    st = 2;
+                } else {
+                    float4 b1 = op[1];
+                    if (COUNT) cNode++;
+                    V3 bmn = mk(b0.x, b0.y, b0.z), bmx = mk(b1.x, b1.y, b1.z);
+                    float E;
+                    bool ok = (__any(flags & F_PAR_WORLD) ? lean_box<true>(t.rayO, winv, bmn, bmx, tMin, E)
+                                                          : lean_box<false>(t.rayO, winv, bmn, bmx, tMin, E)) && (t.closest > E);
+                    if (ok) ok = !(distance_to_aabb(t.rayO, bmn, bmx) > t.closest);
+                    if (ok) {
+                        float4 i0 = op[2], i1 = op[3], i2 = op[4];
+                        t.lo = mk((i0.x * t.rayO.x + i0.y * t.rayO.y) + (i0.z * t.rayO.z + i0.w * 1.0f),
+                                  (i1.x * t.rayO.x + i1.y * t.rayO.y) + (i1.z * t.rayO.z + i1.w * 1.0f),
+                                  (i2.x * t.rayO.x + i2.y * t.rayO.y) + (i2.z * t.rayO.z + i2.w * 1.0f));
+                        t.ld = normalize3(mk((i0.x * t.dirN.x + i0.y * t.dirN.y) + (i0.z * t.dirN.z + i0.w * 0.0f),
+                                             (i1.x * t.dirN.x + i1.y * t.dirN.y) + (i1.z * t.dirN.z + i1.w * 0.0f),
+                                             (i2.x * t.dirN.x + i2.y * t.dirN.y) + (i2.z * t.dirN.z + i2.w * 0.0f)));
+                        flags = lean_inverse(t.ld, t.linv) ? (flags | F_PAR_LOCAL) : (flags & ~F_PAR_LOCAL);
+                        t.sp = 0;
+                        next = root;
+                    } else {
+                        t.obj = (permute && (flags & F_SHADOW)) ? S.nextAny[t.obj] : t.obj + 1;
+                    }
+                }
+            } else if (t.cur >= 0) {
+                const float4* np = reinterpret_cast<const float4*>(S.nodes + t.cur);
+                float4 a = np[0], b = np[1], c = np[2];
+                int2 refs = *reinterpret_cast<const int2*>(np + 3);
+                float EF, ES;
+                bool okF, okS;
+                if (__any(flags & F_PAR_LOCAL)) {
+                    okF = lean_box<true>(t.lo, t.linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
+                    okS = lean_box<true>(t.lo, t.linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
+                } else {
+                    okF = lean_box<false>(t.lo, t.linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
+                    okS = lean_box<false>(t.lo, t.linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
+                }
+                if (COUNT) cNode += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
+                const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (t.closest > EF);
+                const bool canS = refs.y > RT_REF_LIVE_MIN && okS;
+                if (goF) {
+                    if (canS) { stack[t.sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(ES)); ++t.sp; }
+                    next = refs.x;
+                } else if (canS && (t.closest > ES)) {
+                    next = refs.y;
+                } else {
+                    next = lane_pop(t, stack);
+                }
+            } else {
+                int remaining;
+                if (COUNT) cTri++;
+                const bool hit = lane_triangle(S, t, S.objects[t.obj].fwd, ~t.cur, tMin, remaining);
+                if (!COUNT && hit && (flags & F_SHADOW)) { st = 2; t.obj = parentCount; }   // any hit settles a shadow ray
+                else if (remaining <= 1) next = lane_pop(t, stack);
+                else next = t.cur - 1;   // ~(k+1)
+            }
+            if (next == RT_NONE) {   // this object is done: on to the next parent
+                t.obj = (permute && (flags & F_SHADOW)) ? S.nextAny[t.obj] : t.obj + 1;
+                next = RT_WF_BOX;
+            }
+            t.cur = next;
+        }
+    }
+    wf_close(outReg, wf_res(W, 0, 1), wf_res_hole());
+    wf_close(outShd, wf_res(W, 1, 1), wf_res_hole());
+}
+
 // draw = gamma(accum.rgb * 1/total_frames), draw.a = accum.a (raytrace.comp:794-801)
 __global__ __launch_bounds__(256) void RT_SYM(rt_resolve_kernel)(const float4* __restrict__ accum, float4* __restrict__ out,
                                                                  size_t pixels, float multiplier)
@@ -1179,5 +1896,44 @@ extern "C" hipError_t RT_SYM(rt_launch_schedkernel)(const DevScene* S, const rt_
     else
         hipLaunchKernelGGL((RT_SYM(rt_schedkernel)<false, false>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum,
                            (float4*)out, counters, statsOnly, queue, diag);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t RT_SYM(rt_launch_wf_path)(const DevScene* S, const rt_push_constants* pc, const DevLaunch* L,
+                                                const DevWavefront* W, void* accum, void* out, DevCounters* counters,
+                                                int countBuild, int statsOnly, int round, int inlineWalks, int blocks,
+                                                hipStream_t stream)
+{
+    if (L->ownedTiles <= 0 || blocks <= 0) return hipSuccess;
+    const size_t lds = inlineWalks ? (size_t)S->stackDepth * 64 * sizeof(uint2) : 0;
+    dim3 grid((unsigned)blocks), block(64);
+    if (countBuild) {
+        if (inlineWalks)
+            hipLaunchKernelGGL((RT_SYM(rt_wf_path)<true, true>), grid, block, lds, stream, *S, *pc, *L, *W, (float4*)accum,
+                               (float4*)out, counters, statsOnly, round);
+        else
+            hipLaunchKernelGGL((RT_SYM(rt_wf_path)<true, false>), grid, block, lds, stream, *S, *pc, *L, *W, (float4*)accum,
+                               (float4*)out, counters, statsOnly, round);
+    } else {
+        if (inlineWalks)
+            hipLaunchKernelGGL((RT_SYM(rt_wf_path)<false, true>), grid, block, lds, stream, *S, *pc, *L, *W, (float4*)accum,
+                               (float4*)out, counters, statsOnly, round);
+        else
+            hipLaunchKernelGGL((RT_SYM(rt_wf_path)<false, false>), grid, block, lds, stream, *S, *pc, *L, *W, (float4*)accum,
+                               (float4*)out, counters, statsOnly, round);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t RT_SYM(rt_launch_wf_walk)(const DevScene* S, const rt_push_constants* pc, const DevWavefront* W,
+                                                int countBuild, int round, int blocks, hipStream_t stream)
+{
+    if (blocks <= 0) return hipSuccess;
+    const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
+    dim3 grid((unsigned)blocks), block(64);
+    if (countBuild)
+        hipLaunchKernelGGL(RT_SYM(rt_wf_walk)<true>, grid, block, lds, stream, *S, *pc, *W, round);
+    else
+        hipLaunchKernelGGL(RT_SYM(rt_wf_walk)<false>, grid, block, lds, stream, *S, *pc, *W, round);
     return hipGetLastError();
 }

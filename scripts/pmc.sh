@@ -12,8 +12,10 @@ import csv, sys, collections
 f = sys.argv[1]
 acc = collections.defaultdict(lambda: [0.0, 0])
 for row in csv.DictReader(open(f)):
-    if 'kernel' not in row['Kernel_Name'] or 'resolve' in row['Kernel_Name'] or not row['Kernel_Name'].startswith(('void rt_', 'rt_')): continue
-    acc[row['Counter_Name']][0] += float(row['Counter_Value']); acc[row['Counter_Name']][1] += 1
-for k, (v, n) in sorted(acc.items()):
-    print("%-32s per-dispatch %.6g (n=%d)" % (k, v / n, n))
+    k = row['Kernel_Name']
+    if 'rt_' not in k or 'resolve' in k: continue
+    name = k.split('(')[0].replace('void ', '')
+    acc[(name, row['Counter_Name'])][0] += float(row['Counter_Value']); acc[(name, row['Counter_Name'])][1] += 1
+for (name, c), (v, n) in sorted(acc.items()):
+    print("%-36s %-28s sum %.6g  per-dispatch %.6g (n=%d)" % (name, c, v, v / n, n))
 PY

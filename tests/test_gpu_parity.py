@@ -29,9 +29,9 @@ def R():
     return raytracer_amd
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["lockstep", "scheduled"])
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["lockstep", "scheduled", "wavefront"])
 def rdr(R, default_scene_arrays, request):
-    """One renderer per kernel choice: every test that takes `rdr` runs on both pipelines."""
+    """One renderer per kernel choice: every test that takes `rdr` runs on all pipelines."""
     r = R.Renderer(0)
     r.set_option(R.RT_OPT_PIPELINE, request.param)
     r.upload_scene(default_scene_arrays)
@@ -205,7 +205,7 @@ def test_converged_psnr(R, rdr, default_scene_arrays):
     assert psnr >= 45.0, psnr
 
 
-@pytest.mark.parametrize("pipeline", [0, 1], ids=["lockstep", "scheduled"])
+@pytest.mark.parametrize("pipeline", [0, 1, 2], ids=["lockstep", "scheduled", "wavefront"])
 def test_mixed_material_scene(R, pipeline):
     """Glass (exp/pow), mirror, fuzzy metal, emitter, open sky (acos/exp/pow), sub-unit and
     non-uniform scales, a model without normals and one with a 287-triangle leaf."""
@@ -399,6 +399,39 @@ def test_distributed_driver_single_rank(R, default_scene_arrays):
         assert np.array_equal(bits(tgt.accum.cpu().numpy()), bits(o["accum"]))
         assert np.array_equal(bits(tgt.draw.cpu().numpy()), bits(o["out"]))
         tgt.close()
+    finally:
+        r.close()
+
+
+def test_wavefront_knobs_do_not_change_results(R, default_scene_arrays):
+    """The number of suspend/walk/resume rounds, the refill threshold and the grid size of the
+    wavefront pipeline only move work between kernels: every setting gives the lock-step image,
+    also with several samples per pixel, a partial parent count and the counting build."""
+    W, H = 200, 120
+    opc = scenes.make_pc(default_scene_arrays, W, H, raysPerPixel=3, maxBounces=5)
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays)
+        r.set_option(R.RT_OPT_PIPELINE, 0)
+        ref_acc, ref_out = gpu_frames(R, r, opc, [0, 1], W, H)
+        ref_stats = r.frame_stats(to_pc(R, opc))
+        r.set_option(R.RT_OPT_PIPELINE, 2)
+        for rounds, refill, waves in [(0, 16, 12), (1, 64, 12), (2, 1, 3), (5, 16, 12), (12, 32, 16), (30, 48, 1)]:
+            r.set_option(R.RT_OPT_WF_ROUNDS, rounds); r.set_option(R.RT_OPT_WF_REFILL, refill)
+            r.set_option(R.RT_OPT_WAVES_PER_CU, waves)
+            acc, out = gpu_frames(R, r, opc, [0, 1], W, H)
+            assert np.array_equal(bits(acc), bits(ref_acc)), (rounds, refill, waves)
+            assert np.array_equal(bits(out), bits(ref_out)), (rounds, refill, waves)
+            st = r.frame_stats(to_pc(R, opc))
+            assert (st.rays, st.bvhNodeTests, st.triangleTests, st.samples) == \
+                   (ref_stats.rays, ref_stats.bvhNodeTests, ref_stats.triangleTests, ref_stats.samples)
+        # fewer parents than uploaded: shadow rays keep the scene order, walks start at parent 0
+        opc["parentBVHCount"] = 5; opc["raysPerPixel"] = 1
+        r.set_option(R.RT_OPT_WF_ROUNDS, 5); r.set_option(R.RT_OPT_WF_REFILL, 16); r.set_option(R.RT_OPT_WAVES_PER_CU, 12)
+        acc, out = gpu_frames(R, r, opc, [0], W, H)
+        r.set_option(R.RT_OPT_PIPELINE, 0)
+        acc0, out0 = gpu_frames(R, r, opc, [0], W, H)
+        assert np.array_equal(bits(acc), bits(acc0)) and np.array_equal(bits(out), bits(out0))
     finally:
         r.close()
 
