@@ -212,6 +212,22 @@ int rt_scene_model_info(rt_scene* s, const char* model_path, int* triangles, int
  * 1125): clamp to [0,1], x*255+0.5 truncated, alpha forced to 255. */
 void rt_rgba32f_to_rgba8(const float* src, uint8_t* dst, size_t pixel_count);
 
+/* stbi_write_png's role in WriteDrawImageToFile (HardwareRenderer.cpp:1127-1134): an 8-bit RGBA
+ * PNG of width x height tightly packed pixels, row 0 = top. The file is not compressed; a decoder
+ * returns exactly the bytes passed in. */
+int rt_write_png_rgba8(const char* path, const uint8_t* rgba, int width, int height);
+
+/* WriteDrawImageToFile (HardwareRenderer.cpp:1063-1139): read the draw image back, convert it with
+ * rt_rgba32f_to_rgba8 and write it to `path` (the caller chooses the name; the reference uses
+ * Renders\\render_<date>.png). Synchronises. */
+int rt_save_png(rt_ctx* ctx, const char* path);
+
+/* ProduceRender (HardwareRenderer.cpp:1029-1060): dispatches frames pc->frame .. render_frames-1,
+ * advancing pc->frame as the reference advances m_pushConstants.frame, then writes the PNG
+ * (png_path may be NULL: no file) and returns in *seconds the wall-clock time of the whole call,
+ * the number the reference prints as "Render took ... seconds". */
+int rt_produce_render(rt_ctx* ctx, rt_push_constants* pc, int render_frames, const char* png_path, double* seconds);
+
 #ifdef __cplusplus
 }
 #endif

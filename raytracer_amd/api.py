@@ -145,6 +145,8 @@ def load_library():
         "rt_scene_init_default": (ci, [vp, C.c_char_p, C.c_char_p]),
         "rt_scene_model_info": (ci, [vp, C.c_char_p, P(ci), P(ci), P(ci), P(ci)]),
         "rt_rgba32f_to_rgba8": (None, [vp, vp, C.c_size_t]),
+        "rt_write_png_rgba8": (ci, [C.c_char_p, vp, ci, ci]), "rt_save_png": (ci, [vp, C.c_char_p]),
+        "rt_produce_render": (ci, [vp, P(PushConstants), ci, C.c_char_p, P(C.c_double)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol
@@ -161,7 +163,8 @@ EXPORTED_SYMBOLS = [
     "rt_version", "rt_camera_to_push_constants", "rt_default_push_constants", "rt_default_camera", "rt_default_material",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_last_error", "rt_scene_add_material", "rt_scene_material_index",
     "rt_scene_load_model", "rt_scene_add_object", "rt_scene_set_object", "rt_scene_set_material", "rt_scene_buffer_data",
-    "rt_scene_get_buffers", "rt_scene_init_default", "rt_scene_model_info", "rt_rgba32f_to_rgba8"]
+    "rt_scene_get_buffers", "rt_scene_init_default", "rt_scene_model_info", "rt_rgba32f_to_rgba8", "rt_write_png_rgba8",
+    "rt_save_png", "rt_produce_render"]
 
 
 def _f3(v):
@@ -204,6 +207,16 @@ def rgba32f_to_rgba8(img):
     out = np.zeros(img.shape, np.uint8)
     load_library().rt_rgba32f_to_rgba8(img.ctypes.data, out.ctypes.data, img.size // 4)
     return out
+
+
+def write_png_rgba8(path, rgba8):
+    """rt_write_png_rgba8: (H, W, 4) uint8 -> PNG file."""
+    img = np.ascontiguousarray(rgba8, np.uint8)
+    if img.ndim != 3 or img.shape[2] != 4:
+        raise ValueError("expected an (H, W, 4) uint8 image")
+    rc = load_library().rt_write_png_rgba8(str(path).encode(), img.ctypes.data, img.shape[1], img.shape[0])
+    if rc != 0:
+        raise RtError(rc, "cannot write %s" % path)
 
 
 class Scene:
@@ -338,6 +351,18 @@ class Renderer:
         out = (C.c_uint64 * 16)()
         self._check(self.lib.rt_schedule_stats(self.h, C.byref(pc), out))
         return [int(v) for v in out]
+
+    def save_png(self, path):
+        """WriteDrawImageToFile: the draw image as an 8-bit RGBA PNG."""
+        self._check(self.lib.rt_save_png(self.h, str(path).encode()))
+
+    def produce_render(self, pc, render_frames, png_path=None):
+        """ProduceRender: frames pc.frame .. render_frames-1, then the PNG; returns the wall-clock
+        seconds the reference prints. pc.frame is advanced."""
+        sec = C.c_double()
+        self._check(self.lib.rt_produce_render(self.h, C.byref(pc), int(render_frames),
+                                               str(png_path).encode() if png_path is not None else None, C.byref(sec)))
+        return sec.value
 
     def last_render_ms(self):
         a, b = C.c_float(), C.c_float()

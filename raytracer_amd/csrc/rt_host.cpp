@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -795,6 +796,37 @@ int rt_image_size(rt_ctx* ctx, int* width, int* height)
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (width) *width = ctx->width;
     if (height) *height = ctx->height;
+    return RT_OK;
+}
+
+int rt_save_png(rt_ctx* ctx, const char* path)
+{
+    if (!ctx || !path) return fail(ctx, RT_ERR_INVALID_ARG, "rt_save_png: null argument");
+    if (!ctx->draw) return fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
+    const size_t pixels = (size_t)ctx->width * (size_t)ctx->height;
+    std::vector<float> f(pixels * 4);
+    int rc = rt_read_image(ctx, RT_IMAGE_DRAW, f.data(), f.size() * sizeof(float));
+    if (rc != RT_OK) return rc;
+    std::vector<uint8_t> b(pixels * 4);
+    rt_rgba32f_to_rgba8(f.data(), b.data(), pixels);
+    rc = rt_write_png_rgba8(path, b.data(), ctx->width, ctx->height);
+    if (rc != RT_OK) return fail(ctx, rc, std::string("cannot write ") + path);
+    return RT_OK;
+}
+
+int rt_produce_render(rt_ctx* ctx, rt_push_constants* pc, int render_frames, const char* png_path, double* seconds)
+{
+    if (!ctx || !pc) return fail(ctx, RT_ERR_INVALID_ARG, "rt_produce_render: null argument");
+    const auto t0 = std::chrono::system_clock::now();
+    const int first = pc->frame;
+    if (render_frames > first) {
+        int rc = rt_render_frames(ctx, pc, first, 1, render_frames - first);
+        if (rc != RT_OK) return rc;
+        pc->frame = render_frames;
+    }
+    int rc = png_path ? rt_save_png(ctx, png_path) : rt_sync(ctx);
+    if (rc != RT_OK) return rc;
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::system_clock::now() - t0).count();
     return RT_OK;
 }
 

@@ -846,4 +846,74 @@ void rt_rgba32f_to_rgba8(const float* src, uint8_t* dst, size_t pixel_count)
     }
 }
 
+// PNG file with 8-bit RGBA pixels, the format WriteDrawImageToFile hands to stbi_write_png
+// (HardwareRenderer.cpp:1127-1134). The pixel rows go into stored (uncompressed) deflate blocks with
+// filter type 0, so every decoder returns exactly the bytes passed in; only the file size differs
+// from what a compressing writer produces.
+int rt_write_png_rgba8(const char* path, const uint8_t* rgba, int width, int height)
+{
+    if (!path || !rgba || width <= 0 || height <= 0) return RT_ERR_INVALID_ARG;
+    static uint32_t crcTable[256];
+    static bool haveTable = false;
+    if (!haveTable) {
+        for (uint32_t n = 0; n < 256; ++n) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            crcTable[n] = c;
+        }
+        haveTable = true;
+    }
+    auto be32 = [](std::vector<uint8_t>& v, uint32_t x) {
+        v.push_back(uint8_t(x >> 24)); v.push_back(uint8_t(x >> 16)); v.push_back(uint8_t(x >> 8)); v.push_back(uint8_t(x));
+    };
+    std::vector<uint8_t> file = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+    auto chunk = [&](const char type[4], const std::vector<uint8_t>& data) {
+        be32(file, (uint32_t)data.size());
+        const size_t start = file.size();
+        file.insert(file.end(), type, type + 4);
+        file.insert(file.end(), data.begin(), data.end());
+        uint32_t c = 0xffffffffu;
+        for (size_t i = start; i < file.size(); ++i) c = crcTable[(c ^ file[i]) & 0xffu] ^ (c >> 8);
+        be32(file, c ^ 0xffffffffu);
+    };
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, (uint32_t)width); be32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   // 8-bit RGBA, no interlace
+    chunk("IHDR", ihdr);
+
+    const size_t rowBytes = (size_t)width * 4 + 1;   // filter byte + pixels
+    const size_t rawBytes = rowBytes * (size_t)height;
+    std::vector<uint8_t> raw(rawBytes);
+    for (int y = 0; y < height; ++y) {
+        raw[(size_t)y * rowBytes] = 0;
+        std::memcpy(&raw[(size_t)y * rowBytes + 1], rgba + (size_t)y * width * 4, (size_t)width * 4);
+    }
+    uint32_t a = 1, b = 0;   // Adler-32 of the raw stream
+    for (size_t i = 0; i < rawBytes;) {
+        const size_t n = std::min<size_t>(5552, rawBytes - i);
+        for (size_t k = 0; k < n; ++k) { a += raw[i + k]; b += a; }
+        a %= 65521u; b %= 65521u;
+        i += n;
+    }
+    std::vector<uint8_t> z;
+    z.reserve(rawBytes + rawBytes / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    for (size_t i = 0; i < rawBytes;) {
+        const size_t n = std::min<size_t>(65535, rawBytes - i);
+        z.push_back(i + n == rawBytes ? 1 : 0);
+        z.push_back(uint8_t(n)); z.push_back(uint8_t(n >> 8));
+        z.push_back(uint8_t(~n)); z.push_back(uint8_t((~n) >> 8));
+        z.insert(z.end(), raw.begin() + (std::ptrdiff_t)i, raw.begin() + (std::ptrdiff_t)(i + n));
+        i += n;
+    }
+    be32(z, (b << 16) | a);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return RT_ERR_IO;
+    const bool ok = std::fwrite(file.data(), 1, file.size(), f) == file.size();
+    return (std::fclose(f) == 0 && ok) ? RT_OK : RT_ERR_IO;
+}
+
 } // extern "C"

@@ -403,6 +403,28 @@ def test_distributed_driver_single_rank(R, default_scene_arrays):
         r.close()
 
 
+def test_offline_render_and_png(R, rdr, default_scene_arrays, tmp_path):
+    """ProduceRender / WriteDrawImageToFile: frames pc.frame..N-1 accumulate, the frame counter
+    advances, and the PNG holds clamp(x)*255+0.5 of the draw image with alpha 255."""
+    from test_host import decode_png
+    W, H = 96, 54
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    ref_acc, ref_out = gpu_frames(R, rdr, opc, [0, 1, 2], W, H)
+    rdr.clear_accumulation()
+    pc = to_pc(R, opc); pc.frame = 0
+    path = str(tmp_path / "render.png")
+    seconds = rdr.produce_render(pc, 3, path)
+    assert pc.frame == 3 and seconds > 0.0
+    assert np.array_equal(bits(rdr.read_image(R.RT_IMAGE_DRAW)), bits(ref_out))
+    png = decode_png(path)
+    assert np.array_equal(png, R.rgba32f_to_rgba8(ref_out)) and (png[..., 3] == 255).all()
+    # already at the last frame: nothing is dispatched, the image is written again
+    assert rdr.produce_render(pc, 3, path) >= 0.0 and pc.frame == 3
+    assert np.array_equal(decode_png(path), png)
+    rdr.save_png(str(tmp_path / "again.png"))
+    assert np.array_equal(decode_png(str(tmp_path / "again.png")), png)
+
+
 def test_wavefront_knobs_do_not_change_results(R, default_scene_arrays):
     """The number of suspend/walk/resume rounds, the refill threshold and the grid size of the
     wavefront pipeline only move work between kernels: every setting gives the lock-step image,

@@ -121,3 +121,38 @@ def test_no_gpu_means_loud_failure():
     with pytest.raises(R.RtError) as e:
         R.Renderer(0)
     assert e.value.code == -2 and "no CPU path" in str(e.value)
+
+
+def decode_png(path):
+    """Minimal PNG reader for 8-bit RGBA, filter type 0 (what rt_write_png_rgba8 writes), with the
+    chunk CRCs and the zlib checksum verified."""
+    import struct, zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(kind + body) == crc
+        chunks.append((kind, body)); pos += 12 + n
+    assert [k for k, _ in chunks][0] == b"IHDR" and chunks[-1][0] == b"IEND"
+    w, h, depth, colour, comp, flt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, colour, comp, flt, lace) == (8, 6, 0, 0, 0)
+    raw = zlib.decompress(b"".join(b for k, b in chunks if k == b"IDAT"))   # checks the Adler-32
+    rows = np.frombuffer(raw, np.uint8).reshape(h, 1 + 4 * w)
+    assert not rows[:, 0].any()
+    return rows[:, 1:].reshape(h, w, 4)
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (7, 3), (300, 70), (200, 90)])
+def test_png_writer_round_trip(tmp_path, W, H):
+    """The file WriteDrawImageToFile's PNG step produces decodes to the bytes passed in; 300x70 and
+    200x90 cross the 65535-byte stored-block limit."""
+    rng = np.random.default_rng(W * 1000 + H)
+    img = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    path = str(tmp_path / "x.png")
+    api.write_png_rgba8(path, img)
+    assert np.array_equal(decode_png(path), img)
+    with pytest.raises(api.RtError):
+        api.write_png_rgba8(str(tmp_path / "no_such_dir" / "x.png"), img)
