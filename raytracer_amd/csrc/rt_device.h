@@ -42,8 +42,9 @@ struct DevObject {
 };
 
 struct DevNode {
-    float   fmin[3], fmax[3];   /* box of the child visited first */
-    float   smin[3], smax[3];   /* box of the child visited second */
+    float   lo[3][2];           /* lo[axis][c]: box minimum of the child visited first (c = 0) / second (c = 1) */
+    float   hi[3][2];           /* box maximum; the two children sit side by side so that one packed f32
+                                   instruction works on both boxes */
     int32_t first;              /* >=0 DevNode, <0 leaf (~first = DevTri index), RT_REF_ABSENT / RT_REF_EMPTY */
     int32_t second;
     int32_t pad[2];

@@ -239,18 +239,18 @@ struct Relayout {
         if (!childRef(first, depth + 1, fr, hf)) return false;
         if (!childRef(second, depth + 1, sr, hs)) return false;
         DevNode n{};
-        auto box = [&](int node, float mn[3], float mx[3]) {
-            if (node == -1) { mn[0] = mn[1] = mn[2] = 0.0f; mx[0] = mx[1] = mx[2] = 0.0f; return; }
-            mn[0] = bmin[node].x; mn[1] = bmin[node].y; mn[2] = bmin[node].z;
-            mx[0] = bmax[node].x; mx[1] = bmax[node].y; mx[2] = bmax[node].z;
+        auto box = [&](int node, int c) {
+            if (node == -1) return;   // stays all zero
+            n.lo[0][c] = bmin[node].x; n.lo[1][c] = bmin[node].y; n.lo[2][c] = bmin[node].z;
+            n.hi[0][c] = bmax[node].x; n.hi[1][c] = bmax[node].y; n.hi[2][c] = bmax[node].z;
         };
-        box(first, n.fmin, n.fmax);
-        box(second, n.smin, n.smax);
+        box(first, 0);
+        box(second, 1);
         // a box with min > max on an axis can never be entered (raytrace.comp:221,239): keep it
         // counted but dead, so the kernels may take the slab interval by min/max of the planes
-        auto inverted = [](const float mn[3], const float mx[3]) { return mn[0] > mx[0] || mn[1] > mx[1] || mn[2] > mx[2]; };
-        if (fr != RT_REF_ABSENT && inverted(n.fmin, n.fmax)) fr = RT_REF_DEAD;
-        if (sr != RT_REF_ABSENT && inverted(n.smin, n.smax)) sr = RT_REF_DEAD;
+        auto inverted = [&](int c) { return n.lo[0][c] > n.hi[0][c] || n.lo[1][c] > n.hi[1][c] || n.lo[2][c] > n.hi[2][c]; };
+        if (fr != RT_REF_ABSENT && inverted(0)) fr = RT_REF_DEAD;
+        if (sr != RT_REF_ABSENT && inverted(1)) sr = RT_REF_DEAD;
         n.first = fr;
         n.second = sr;
         dNodes[idx] = n;

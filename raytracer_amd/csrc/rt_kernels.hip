@@ -254,6 +254,51 @@ __device__ __forceinline__ bool lean_box(V3 o, V3 inv, V3 mn, V3 mx, float tMin,
     return ok && (x > e);
 }
 
+// One visit of a two-child record: both children's slab tests (lean_box) at once. The record keeps
+// the two boxes side by side per plane, so the plane distances of both children come out of packed
+// f32 subtracts and multiplies (two IEEE operations per instruction, same results as the scalar
+// form); the interval logic stays per child.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct NodeVisit { bool okF, okS; float EF, ES; int2 refs; };
+
+template <bool PAR>
+__device__ __forceinline__ void node_boxes(const DevNode* node, V3 o, V3 inv, float tMin, NodeVisit& r)
+{
+    const float4* np = reinterpret_cast<const float4*>(node);
+    const float4 a = np[0], b = np[1], c = np[2];
+    r.refs = *reinterpret_cast<const int2*>(np + 3);
+    const f32x2 lox = { a.x, a.y }, loy = { a.z, a.w }, loz = { b.x, b.y };
+    const f32x2 hix = { b.z, b.w }, hiy = { c.x, c.y }, hiz = { c.z, c.w };
+    const f32x2 ox = { o.x, o.x }, oy = { o.y, o.y }, oz = { o.z, o.z };
+    const f32x2 ix = { inv.x, inv.x }, iy = { inv.y, inv.y }, iz = { inv.z, inv.z };
+    const f32x2 t0x = (lox - ox) * ix, t1x = (hix - ox) * ix;
+    const f32x2 t0y = (loy - oy) * iy, t1y = (hiy - oy) * iy;
+    const f32x2 t0z = (loz - oz) * iz, t1z = (hiz - oz) * iz;
+    float eF = tMin, xF = INFINITY, eS = tMin, xS = INFINITY;
+    eF = fmaxf(eF, fminf(t0x.x, t1x.x)); xF = fminf(xF, fmaxf(t0x.x, t1x.x));
+    eS = fmaxf(eS, fminf(t0x.y, t1x.y)); xS = fminf(xS, fmaxf(t0x.y, t1x.y));
+    eF = fmaxf(eF, fminf(t0y.x, t1y.x)); xF = fminf(xF, fmaxf(t0y.x, t1y.x));
+    eS = fmaxf(eS, fminf(t0y.y, t1y.y)); xS = fminf(xS, fmaxf(t0y.y, t1y.y));
+    eF = fmaxf(eF, fminf(t0z.x, t1z.x)); xF = fminf(xF, fmaxf(t0z.x, t1z.x));
+    eS = fmaxf(eS, fminf(t0z.y, t1z.y)); xS = fminf(xS, fmaxf(t0z.y, t1z.y));
+    bool okF = true, okS = true;
+    if (PAR) {
+        // an axis the ray runs parallel to (NaN reciprocal): the origin must lie between the planes
+        if (inv.x != inv.x) { okF = okF && !(o.x < lox.x || o.x > hix.x); okS = okS && !(o.x < lox.y || o.x > hix.y); }
+        if (inv.y != inv.y) { okF = okF && !(o.y < loy.x || o.y > hiy.x); okS = okS && !(o.y < loy.y || o.y > hiy.y); }
+        if (inv.z != inv.z) { okF = okF && !(o.z < loz.x || o.z > hiz.x); okS = okS && !(o.z < loz.y || o.z > hiz.y); }
+    }
+    r.EF = eF; r.ES = eS;
+    r.okF = okF && (xF > eF);
+    r.okS = okS && (xS > eS);
+}
+
+__device__ __forceinline__ void visit_node(const DevScene& S, int cur, V3 o, V3 inv, bool anyParallel, float tMin, NodeVisit& r)
+{
+    if (anyParallel) node_boxes<true>(S.nodes + cur, o, inv, tMin, r);
+    else node_boxes<false>(S.nodes + cur, o, inv, tMin, r);
+}
+
 struct Counters { int rays, nodeTests, triTests; };
 
 // What a GetHit call keeps while it walks: enough to rebuild the RayHit.
@@ -306,29 +351,35 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
         int sp = 0;
 
         for (;;) {
-            if (cur >= 0) {
-                const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-                float4 a = np[0], b = np[1], c = np[2];
-                int2 refs = *reinterpret_cast<const int2*>(np + 3);
-                float EF, ES;
-                bool okF, okS;
-                if (__any(parL)) {
-                    okF = lean_box<true>(lo, linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
-                    okS = lean_box<true>(lo, linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
-                } else {
-                    okF = lean_box<false>(lo, linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
-                    okS = lean_box<false>(lo, linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
-                }
+            // Descent. A lane that reaches a leaf leaves this loop and waits for the others, so
+            // that the triangle tests below run once for all the leaves the wave has reached
+            // rather than once per lane (each lane still performs its own steps in its own order).
+            while ((unsigned)cur < (unsigned)RT_NONE) {
+                NodeVisit nv;
+                visit_node(S, cur, lo, linv, __any(parL), tMin, nv);
+                const int2 refs = nv.refs;
+                const float EF = nv.EF, ES = nv.ES;
+                const bool okF = nv.okF, okS = nv.okS;
                 if (COUNT) cnt.nodeTests += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
                 bool goF = refs.x > RT_REF_LIVE_MIN && okF && (best.closest > EF);
                 bool canS = refs.y > RT_REF_LIVE_MIN && okS;
                 if (goF) {
                     if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(ES)); ++sp; }
                     cur = refs.x;
-                    continue;
+                } else if (canS && (best.closest > ES)) {
+                    cur = refs.y;
+                } else {
+                    // pop: discard entries whose box no longer reaches inside the closest hit
+                    cur = RT_NONE;
+                    while (sp > 0) {
+                        --sp;
+                        uint2 e = stack[sp * 64];
+                        if (best.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                    }
                 }
-                if (canS && (best.closest > ES)) { cur = refs.y; continue; }
-            } else {
+            }
+            if (cur == RT_NONE) break;
+            {
                 int k = ~cur;
                 for (;;) {
                     const float4* tp = reinterpret_cast<const float4*>(S.tris + k);
@@ -867,18 +918,11 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
                         t.sp = 0;
                         next = __float_as_int(b0.w);
                     } else if (t.cur >= 0) {
-                        const float4* np = reinterpret_cast<const float4*>(S.nodes + t.cur);
-                        float4 a = np[0], b = np[1], c = np[2];
-                        int2 refs = *reinterpret_cast<const int2*>(np + 3);
-                        float EF, ES;
-                        bool okF, okS;
-                        if (__any(flags & F_PAR_LOCAL)) {
-                            okF = lean_box<true>(t.lo, t.linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
-                            okS = lean_box<true>(t.lo, t.linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
-                        } else {
-                            okF = lean_box<false>(t.lo, t.linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
-                            okS = lean_box<false>(t.lo, t.linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
-                        }
+                        NodeVisit nv;
+                        visit_node(S, t.cur, t.lo, t.linv, __any(flags & F_PAR_LOCAL), tMin, nv);
+                        const int2 refs = nv.refs;
+                        const float EF = nv.EF, ES = nv.ES;
+                        const bool okF = nv.okF, okS = nv.okS;
                         if (COUNT) cNode += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
                         const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (t.closest > EF);
                         const bool canS = refs.y > RT_REF_LIVE_MIN && okS;
@@ -1152,18 +1196,11 @@ __device__ __forceinline__ bool walk_in_place(const DevScene& S, const DevObject
     int sp = 0;
     for (;;) {
         if (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-            float4 a = np[0], b = np[1], c = np[2];
-            int2 refs = *reinterpret_cast<const int2*>(np + 3);
-            float EF, ES;
-            bool okF, okS;
-            if (__any(parL)) {
-                okF = lean_box<true>(lo, linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
-                okS = lean_box<true>(lo, linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
-            } else {
-                okF = lean_box<false>(lo, linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
-                okS = lean_box<false>(lo, linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
-            }
+            NodeVisit nv;
+            visit_node(S, cur, lo, linv, __any(parL), tMin, nv);
+            const int2 refs = nv.refs;
+            const float EF = nv.EF, ES = nv.ES;
+            const bool okF = nv.okF, okS = nv.okS;
             if (COUNT) cnt.nodeTests += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
             const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (best.closest > EF);
             const bool canS = refs.y > RT_REF_LIVE_MIN && okS;
@@ -1791,18 +1828,11 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
                     }
                 }
             } else if (t.cur >= 0) {
-                const float4* np = reinterpret_cast<const float4*>(S.nodes + t.cur);
-                float4 a = np[0], b = np[1], c = np[2];
-                int2 refs = *reinterpret_cast<const int2*>(np + 3);
-                float EF, ES;
-                bool okF, okS;
-                if (__any(flags & F_PAR_LOCAL)) {
-                    okF = lean_box<true>(t.lo, t.linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
-                    okS = lean_box<true>(t.lo, t.linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
-                } else {
-                    okF = lean_box<false>(t.lo, t.linv, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), tMin, EF);
-                    okS = lean_box<false>(t.lo, t.linv, mk(b.z, b.w, c.x), mk(c.y, c.z, c.w), tMin, ES);
-                }
+                NodeVisit nv;
+                visit_node(S, t.cur, t.lo, t.linv, __any(flags & F_PAR_LOCAL), tMin, nv);
+                const int2 refs = nv.refs;
+                const float EF = nv.EF, ES = nv.ES;
+                const bool okF = nv.okF, okS = nv.okS;
                 if (COUNT) cNode += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
                 const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (t.closest > EF);
                 const bool canS = refs.y > RT_REF_LIVE_MIN && okS;
