@@ -95,31 +95,26 @@ struct DevLaunch {
     int32_t biasObject, biasTrav, biasShade, quorumMin, quorumDiv;
 };
 
-/* Buffers of the wavefront pipeline. A ray that must walk a BVH becomes a job: a record spread
- * over RT_WF_JOB_ARRAYS arrays of 16-byte parts, indexed by its position in the round's job list,
- * so that consecutive lanes write and read consecutive addresses:
- *   0 ray origin, pixel slot (-1: unused entry)   1 ray direction, object to walk | shadow << 31
+/* Buffers of the wavefront pipeline. A ray that leaves the path kernel becomes a job: a record
+ * spread over RT_WF_JOB_ARRAYS arrays of 16-byte parts, indexed by its position in the round's job
+ * list, so that consecutive lanes write and read consecutive addresses:
+ *   0 ray origin, pixel slot (-1: unused entry)   1 ray direction, object to walk | start << 30 | shadow << 31
  *   2 closest, hitT, u, v                         3 best object + 1, best triangle, node tests, triangle tests
  *   4 throughput, sample                          5 result, bounce
  *   6 pending sun term   7 pending origin   8 pending direction           (shadow rays)
  *   9 pixel sum, GetHit calls                                             (raysPerPixel > 1, counting)
- * The walk kernel reads parts 0-3 and answers with a result record (RT_WF_RES_ARRAYS parts) in the
- * list of the ray's kind (0 regular, 1 shadow):
- *   0 closest, hitT, u, v    1 (best object + 1) | next object << 16, best triangle, job index (-1: unused), node tests
- *   2 triangle tests (counting build)
- * The path kernel of the next round reads the result and, through the job index, the rest. Job
- * buffers alternate between rounds; the lists of a round hold at most one job per pixel plus one
- * partly used block per resident wave. */
+ * The walk kernel reads parts 0-3 and writes its answer back into parts 2 and 3 (part 3's first word
+ * becomes (best object + 1) | next object << 16); the path kernel of the next round reads the list
+ * in order. Job buffers alternate between rounds; a round's list holds at most one job per pixel
+ * plus one partly used block per resident wave. */
 #define RT_WF_JOB_ARRAYS 10
-#define RT_WF_RES_ARRAYS 3
 #define RT_WF_MAX_ROUNDS 30
-#define RT_WF_WORDS_PER_ROUND 8   /* 0 jobs, 1 job head, 2 results regular, 3 results shadow, 4 result chunk head */
+#define RT_WF_WORDS_PER_ROUND 8   /* 0 jobs, 1 job head (walk kernel), 4 chunk head (path kernel of the next round) */
 struct DevWavefront {
     void*     jobs[2];      /* RT_WF_JOB_ARRAYS * listCap float4 each; round r uses jobs[r & 1] */
-    void*     results;      /* 2 kinds * RT_WF_RES_ARRAYS * listCap float4 */
     uint32_t* counts;       /* (RT_WF_MAX_ROUNDS + 2) * RT_WF_WORDS_PER_ROUND words, zeroed per dispatch */
     int32_t   listCap;
-    int32_t   refillMin;    /* a walking wave fetches new rays when this many lanes are free */
+    int32_t   refillMin;    /* a walking wave fetches new jobs when this many lanes are free */
 };
 
 struct DevCounters {

@@ -342,7 +342,7 @@ int checkRenderable(rt_ctx* ctx, const rt_push_constants* pc)
     return RT_OK;
 }
 
-// One allocation: control words, two job buffers, the result lists.
+// One allocation: control words and two job buffers.
 int ensureWavefront(rt_ctx* ctx)
 {
     const size_t slots = (size_t)ctx->width * (size_t)ctx->height;
@@ -356,13 +356,11 @@ int ensureWavefront(rt_ctx* ctx)
     const size_t ctlBytes = 4096;
     static_assert((RT_WF_MAX_ROUNDS + 2) * RT_WF_WORDS_PER_ROUND * sizeof(uint32_t) <= 4096, "control block");
     const size_t jobBytes = (size_t)RT_WF_JOB_ARRAYS * listCap * 16;
-    const size_t resBytes = (size_t)2 * RT_WF_RES_ARRAYS * listCap * 16;
-    RT_HIP(ctx, hipMalloc(&ctx->wfMem, ctlBytes + 2 * jobBytes + resBytes));
+    RT_HIP(ctx, hipMalloc(&ctx->wfMem, ctlBytes + 2 * jobBytes));
     char* base = static_cast<char*>(ctx->wfMem);
     ctx->wf.counts = reinterpret_cast<uint32_t*>(base);
     ctx->wf.jobs[0] = base + ctlBytes;
     ctx->wf.jobs[1] = base + ctlBytes + jobBytes;
-    ctx->wf.results = base + ctlBytes + 2 * jobBytes;
     ctx->wf.listCap = (int32_t)listCap;
     ctx->wfSlots = slots;
     return RT_OK;

@@ -1169,15 +1169,16 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
 //   rt_wf_path   round 0: one lane per pixel - camera ray and the first part of GetHit's object
 //                loop (parent boxes, leaf parents such as the six walls) up to the first BVH
 //                parent the ray enters;
-//                round r > 0: takes the rays whose walk has finished and runs, for 64 of them in
+//                round r > 0: takes the jobs of round r-1, walked, and runs, for 64 of them in
 //                step, the rest of the object loop, shading, the shadow ray and the start of the
-//                next ray (regular and shadow rays come in separate lists so that a wave stays in
-//                step);
+//                next ray;
 //                last round: BVH parents are walked in place, so nothing is left over.
 //   rt_wf_walk   walks the BVH parent a job has entered and the BVH parents that follow it in the
 //                object loop. Every lane runs its own small state machine (one parent box / one
 //                two-child record / one triangle per step) and takes the next job from the list
-//                when it is done, so the wave stays full whatever the lengths of the walks.
+//                when it is done, so the wave stays full whatever the lengths of the walks. The
+//                answer is written back into the job's own record, so the next round of the path
+//                kernel reads jobs and answers in list order, with consecutive addresses.
 // Kernel boundaries on one stream order the hand-over of jobs and results; within a kernel only
 // atomic counters are shared. Per ray the arithmetic and its order are those of the lock-step
 // kernel, so the images are the same bit for bit.
@@ -1373,12 +1374,7 @@ __device__ __forceinline__ float4* wf_job(const DevWavefront& W, int parity, int
 {
     return reinterpret_cast<float4*>(W.jobs[parity]) + (size_t)part * (size_t)W.listCap;
 }
-__device__ __forceinline__ float4* wf_res(const DevWavefront& W, int kind, int part)
-{
-    return reinterpret_cast<float4*>(W.results) + (size_t)(kind * RT_WF_RES_ARRAYS + part) * (size_t)W.listCap;
-}
 __device__ __forceinline__ float4 wf_job_hole() { return make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); }
-__device__ __forceinline__ float4 wf_res_hole() { return make_float4(0.0f, 0.0f, __int_as_float(-1), 0.0f); }
 
 struct PathVars {
     V3 rayO, rayD;
@@ -1443,13 +1439,11 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_con
     WaveBlock blk;
     blk.base = 0; blk.left = 0;
     unsigned grabNext = 0, grabLeft = 0;
-    unsigned nReg = 0, nShd = 0, chunksReg = 0, chunks = 0;
+    unsigned jobsIn = 0, chunks = 0;
     uint32_t* workCounter;
     if (round > 0) {
-        nReg = W.counts[(round - 1) * RT_WF_WORDS_PER_ROUND + 2];
-        nShd = W.counts[(round - 1) * RT_WF_WORDS_PER_ROUND + 3];
-        chunksReg = (nReg + 63u) >> 6;
-        chunks = chunksReg + ((nShd + 63u) >> 6);
+        jobsIn = W.counts[(round - 1) * RT_WF_WORDS_PER_ROUND + 0];
+        chunks = (jobsIn + 63u) >> 6;
         workCounter = &W.counts[(round - 1) * RT_WF_WORDS_PER_ROUND + 4];
     } else {
         const int wavesX = L.tileSize >> 3;
@@ -1458,7 +1452,7 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_con
     }
 
     for (;;) {
-        // ---- lanes of this pass: a pixel tile (round 0) or 64 results ----
+        // ---- lanes of this pass: a pixel tile (round 0) or 64 jobs of the previous round, walked ----
         // (chunks are taken four at a time: atomics on one address are served one by one)
         if (grabLeft == 0) {
             unsigned g = 0;
@@ -1470,7 +1464,7 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_con
         ++grabNext; --grabLeft;
         if (chunk >= chunks) break;
 
-        int entry = 0;          // 0 new path, 1 back from a regular ray's walk, 2 back from a shadow ray's walk
+        int kind = 0;           // per lane: 0 new path, 1 back from a regular ray's walk, 2 back from a shadow ray's walk
         bool alive = false;
         int slot = 0, px = 0, py = 0;
         int resumeObj = 0;                       // object at which a resumed GetHit call continues
@@ -1504,34 +1498,28 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_con
                 v.rayO = r0.o; v.rayD = r0.d;
             }
         } else {
-            const int kind = chunk >= chunksReg ? 1 : 0;
-            const unsigned i = (kind ? chunk - chunksReg : chunk) * 64u + (unsigned)lane;
-            entry = kind + 1;
-            int job = -1;
-            float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0;
-            if (i < (kind ? nShd : nReg)) {
-                r0 = wf_res(W, kind, 0)[i];
-                r1 = wf_res(W, kind, 1)[i];
-                job = __float_as_int(r1.z);
-            }
-            alive = job >= 0;
+            const unsigned job = chunk * 64u + (unsigned)lane;
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+            if (job < jobsIn) a = wf_job(W, prev, 0)[job];
+            slot = __float_as_int(a.w);
+            alive = slot >= 0;   // -1: unused entry of a writer's block
             if (alive) {
-                float4 a = wf_job(W, prev, 0)[job], e = wf_job(W, prev, 4)[job], f = wf_job(W, prev, 5)[job];
-                slot = __float_as_int(a.w);
+                float4 b = wf_job(W, prev, 1)[job], r0 = wf_job(W, prev, 2)[job], r1 = wf_job(W, prev, 3)[job];
+                float4 e = wf_job(W, prev, 4)[job], f = wf_job(W, prev, 5)[job];
+                kind = (__float_as_uint(b.w) & 0x80000000u) ? 2 : 1;
                 py = slot / L.width; px = slot - py * L.width;
                 best.closest = r0.x; best.tLocal = r0.y; best.u = r0.z; best.v = r0.w;
                 best.object = (__float_as_int(r1.x) & 0xffff) - 1; best.tri = __float_as_int(r1.y);
                 resumeObj = (int)((unsigned)__float_as_int(r1.x) >> 16);
-                if (COUNT) { cnt.nodeTests = __float_as_int(r1.w); cnt.triTests = __float_as_int(wf_res(W, kind, 2)[i].x); }
+                if (COUNT) { cnt.nodeTests = __float_as_int(r1.z); cnt.triTests = __float_as_int(r1.w); }
                 v.throughput = mk(e.x, e.y, e.z); v.sample = __float_as_int(e.w);
                 v.result = mk(f.x, f.y, f.z); v.bounce = __float_as_int(f.w);
                 seed = seed_from_coords((uint32_t)px, (uint32_t)py, (uint32_t)pc.frame, (uint32_t)v.sample);
-                if (kind) {
+                if (kind == 2) {
                     float4 g = wf_job(W, prev, 6)[job], h = wf_job(W, prev, 7)[job], k = wf_job(W, prev, 8)[job];
                     v.pendD = mk(g.x, g.y, g.z); v.pendO = mk(h.x, h.y, h.z); v.pendDir = mk(k.x, k.y, k.z);
                     resumeO = mk(a.x, a.y, a.z);
                 } else {
-                    float4 b = wf_job(W, prev, 1)[job];
                     v.rayO = mk(a.x, a.y, a.z); v.rayD = mk(b.x, b.y, b.z);
                 }
                 if (wide) {
@@ -1547,31 +1535,34 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_con
             bool pathEnd = false, needShadow = false;
             V3 so = v.rayO;
             const V3 negSun = -ld3(pc.sunDirection);
-            if (!(firstPass && entry == 2)) {
-                V3 dirN = normalize3(v.rayD);
-                {
-                    const bool fresh = !(firstPass && entry == 1);
-                    if (!INLINE && fresh && leadingBvh) {
-                        // a ray that has just started, in a scene whose first parent is a BVH parent:
-                        // the walk kernel starts its GetHit call, box test of that parent included
-                        best.closest = 1e20f; best.object = -1; best.tri = 0; best.u = 0.0f; best.v = 0.0f; best.tLocal = 0.0f;
-                        if (COUNT && alive) cnt.rays++;
-                        wf_emit(W, round, blk, alive, slot, false, 0x40000000, v.rayO, v.rayD, best, v, cnt, wide);
-                        alive = false;
-                    } else {
-                        int obj = -1;
-                        if (alive)
-                            obj = trace_until_walk<COUNT, INLINE>(S, parentCount, false, fresh, resumeObj, v.rayO, dirN, tMin, best, cnt, stack);
-                        if (!INLINE) {
-                            // a ray that has just started leaves in any case; one that came back from a
-                            // walk leaves only if it enters another BVH parent
-                            const bool emit = alive && (fresh || obj >= 0);
-                            wf_emit(W, round, blk, emit, slot, false, obj >= 0 ? obj : parentCount, v.rayO, v.rayD, best, v, cnt, wide);
-                            if (emit) alive = false;
-                        }
-                    }
+            // in the first pass of a resume round every lane continues a call it came back from:
+            // regular rays here, shadow rays further down
+            const bool fresh = !(firstPass && round > 0);
+            const bool backShd = !fresh && kind == 2;
+            const bool inReg = alive && !backShd;
+            const V3 dirN = normalize3(v.rayD);
+            if (!INLINE && fresh && leadingBvh) {
+                // rays that have just started, in a scene whose first parent is a BVH parent: the
+                // walk kernel starts their GetHit call, box test of that parent included
+                best.closest = 1e20f; best.object = -1; best.tri = 0; best.u = 0.0f; best.v = 0.0f; best.tLocal = 0.0f;
+                if (COUNT && inReg) cnt.rays++;
+                wf_emit(W, round, blk, inReg, slot, false, 0x40000000, v.rayO, v.rayD, best, v, cnt, wide);
+                if (inReg) alive = false;
+            } else {
+                int obj = -1;
+                if (inReg)
+                    obj = trace_until_walk<COUNT, INLINE>(S, parentCount, false, fresh, resumeObj, v.rayO, dirN, tMin, best, cnt, stack);
+                if (!INLINE) {
+                    // a ray that has just started leaves in any case; one that came back from a
+                    // walk leaves only if it enters another BVH parent
+                    const bool emit = inReg && (fresh || obj >= 0);
+                    wf_emit(W, round, blk, emit, slot, false, obj >= 0 ? obj : parentCount, v.rayO, v.rayD, best, v, cnt, wide);
+                    if (emit) alive = false;
                 }
-                if (alive) {
+            }
+            if (backShd) needShadow = alive;   // back from the walk of a shadow ray
+            {
+                if (inReg && alive) {
                     HitRec rec;
                     finish_hit(S, v.rayO, dirN, best, rec);
                     if (!rec.hit) {
@@ -1604,16 +1595,13 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_con
                         }
                     }
                 }
-            } else {
-                needShadow = alive;   // back from the walk of a shadow ray
             }
             // ShadowTransmission, raytrace.comp:612-621,733-753
             if (__any(needShadow)) {
-                const bool fresh = !(firstPass && entry == 2);
-                if (!fresh) so = resumeO;
+                if (backShd) so = resumeO;
                 int obj = -1;
                 if (needShadow)
-                    obj = trace_until_walk<COUNT, INLINE>(S, parentCount, true, fresh, resumeObj, so, normalize3(negSun), tMin, best, cnt, stack);
+                    obj = trace_until_walk<COUNT, INLINE>(S, parentCount, true, !backShd, resumeObj, so, normalize3(negSun), tMin, best, cnt, stack);
                 if (!INLINE) {
                     const bool emit = needShadow && obj >= 0;
                     wf_emit(W, round, blk, emit, slot, true, obj, so, negSun, best, v, cnt, wide);
@@ -1713,27 +1701,16 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
     t.closest = 1e20f; t.bestT = t.bestU = t.bestV = 0.0f; t.bestObj = -1; t.bestTri = 0;
     t.obj = 0; t.cur = RT_WF_BOX; t.sp = 0;
     bool exhausted = false;   // wave-uniform: the list has no more entries
-    WaveBlock outReg, outShd;   // this wave's blocks in the two result lists
-    outReg.base = outReg.left = outShd.base = outShd.left = 0;
     unsigned inNext = 0, inLeft = 0;   // this wave's range of the job list
 
     for (;;) {
         const int walking = __popcll(__ballot(st == 1));
         if (walking == 0 || (!exhausted && walking <= 64 - refillMin)) {
-            // hand finished rays on: a result record in the list of the ray's kind
-            const bool fin = st == 2;
-            const unsigned long long mReg = __ballot(fin && !(flags & F_SHADOW));
-            const unsigned long long mShd = __ballot(fin && (flags & F_SHADOW));
-            unsigned iReg = 0, iShd = 0;
-            if (mReg) iReg = wf_append(outReg, &ctl[2], wf_res(W, 0, 1), wf_res_hole(), mReg);
-            if (mShd) iShd = wf_append(outShd, &ctl[3], wf_res(W, 1, 1), wf_res_hole(), mShd);
-            if (fin) {
-                const int kind = (flags & F_SHADOW) ? 1 : 0;
-                const unsigned i = kind ? iShd : iReg;
-                wf_res(W, kind, 0)[i] = make_float4(t.closest, t.bestT, t.bestU, t.bestV);
-                wf_res(W, kind, 1)[i] = make_float4(__int_as_float((t.bestObj + 1) | (t.obj << 16)), __int_as_float(t.bestTri),
-                                                    __int_as_float(job), __int_as_float(cNode));
-                if (COUNT) wf_res(W, kind, 2)[i] = make_float4(__int_as_float(cTri), 0.0f, 0.0f, 0.0f);
+            // hand finished rays on: the answer goes back into parts 2 and 3 of the job's own record
+            if (st == 2) {
+                wf_job(W, par, 2)[job] = make_float4(t.closest, t.bestT, t.bestU, t.bestV);
+                wf_job(W, par, 3)[job] = make_float4(__int_as_float((t.bestObj + 1) | (t.obj << 16)), __int_as_float(t.bestTri),
+                                                     __int_as_float(cNode), __int_as_float(cTri));
                 st = 0;
             }
             // take new jobs from the list, of which this wave reserves 256 entries at a time
@@ -1859,8 +1836,6 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
             t.cur = next;
         }
     }
-    wf_close(outReg, wf_res(W, 0, 1), wf_res_hole());
-    wf_close(outShd, wf_res(W, 1, 1), wf_res_hole());
 }
 
 // draw = gamma(accum.rgb * 1/total_frames), draw.a = accum.a (raytrace.comp:794-801)

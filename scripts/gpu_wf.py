@@ -13,5 +13,6 @@ def run(rounds, refill, waves):
     r.render_frames(pc, 0, 1, 4); r.sync()
     r.render_frames(pc, 0, 1, 8); r.sync()
     print("rounds %2d refill %2d waves/CU %2d : %.2f ms/frame" % (rounds, refill, waves, r.last_render_ms()[1]), flush=True)
-for cfg in [(5, 16, 12), (5, 32, 12), (5, 64, 12), (5, 64, 8), (5, 64, 16), (3, 64, 12), (8, 64, 12), (1, 64, 12), (0, 64, 12)]:
+cfgs = [tuple(int(x) for x in a.split(',')) for a in sys.argv[3:]] or [(5, 16, 12), (5, 8, 12), (5, 32, 12), (5, 16, 14), (5, 16, 16), (5, 8, 14), (4, 16, 12)]
+for cfg in cfgs:
     run(*cfg)
