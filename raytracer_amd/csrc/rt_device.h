@@ -113,6 +113,7 @@ struct DevLaunch {
 struct DevWavefront {
     void*     jobs[2];      /* RT_WF_JOB_ARRAYS * listCap float4 each; round r uses jobs[r & 1] */
     uint32_t* counts;       /* (RT_WF_MAX_ROUNDS + 2) * RT_WF_WORDS_PER_ROUND words, zeroed per dispatch */
+    void*     deepStack;    /* per walking wave: the traversal stack levels that do not fit its LDS share */
     int32_t   listCap;
     int32_t   refillMin;    /* a walking wave fetches new jobs when this many lanes are free */
 };

@@ -78,11 +78,16 @@ struct rt_ctx {
     int wavesPerCU = 12;
     int policy[5] = { 0, 0, 0, 4, 8 };   // biasObject, biasTrav, biasShade, quorumMin, quorumDiv
 
-    // wavefront pipeline: ray state and lists, sized for the current image
-    DevWavefront wf{};
-    void* wfMem = nullptr;
-    size_t wfSlots = 0;
-    int wfRounds = 5, wfRefill = 16;
+    // wavefront pipeline: the image is dealt out to wfParts independent partitions (tile split inside
+    // one GPU), each with its own job buffers and stream, so that the thin end of one partition's
+    // kernels overlaps with the bulk of another's
+    static const int kMaxParts = 8;
+    DevWavefront wf[kMaxParts]{};
+    void* wfMem[kMaxParts] = {};
+    hipStream_t wfStream[kMaxParts] = {};
+    hipEvent_t wfFork = nullptr, wfJoin[kMaxParts] = {};
+    size_t wfKey[6] = {};
+    int wfRounds = 5, wfRefill = 16, wfWalkWaves = 12, wfParts = 3;
 
     int optFast = 0, optPipeline = 0, tileRank = 0, tileWorld = 1, tileSize = 64;
     std::string error;
@@ -122,10 +127,12 @@ void freeScene(rt_ctx* c)
 
 void freeWavefront(rt_ctx* c)
 {
-    if (c->wfMem) (void)hipFree(c->wfMem);
-    c->wfMem = nullptr;
-    c->wfSlots = 0;
-    c->wf = DevWavefront{};
+    for (int k = 0; k < rt_ctx::kMaxParts; ++k) {
+        if (c->wfMem[k]) (void)hipFree(c->wfMem[k]);
+        c->wfMem[k] = nullptr;
+        c->wf[k] = DevWavefront{};
+    }
+    for (size_t& x : c->wfKey) x = 0;
 }
 
 void freeImages(rt_ctx* c)
@@ -303,7 +310,7 @@ struct Relayout {
 int uploadArray(rt_ctx* ctx, void** dst, const void* src, size_t bytes)
 {
     *dst = nullptr;
-    const size_t alloc = std::max<size_t>(bytes, 256);
+    const size_t alloc = std::max<size_t>(bytes, 256) + 64;   // the walk kernel fetches 64 bytes at every record's address
     RT_HIP(ctx, hipMalloc(dst, alloc));
     RT_HIP(ctx, hipMemsetAsync(*dst, 0, alloc, ctx->stream));
     if (bytes) RT_HIP(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -342,64 +349,105 @@ int checkRenderable(rt_ctx* ctx, const rt_push_constants* pc)
     return RT_OK;
 }
 
-// One allocation: control words and two job buffers.
-int ensureWavefront(rt_ctx* ctx)
+DevLaunch partLaunch(const DevLaunch& L, int part, int parts)
 {
-    const size_t slots = (size_t)ctx->width * (size_t)ctx->height;
-    if (ctx->wfMem && ctx->wfSlots == slots) return RT_OK;
+    DevLaunch P = L;
+    P.tileRank = L.tileRank + part * L.tileWorld;
+    P.tileWorld = L.tileWorld * parts;
+    const int total = L.tilesX * L.tilesY;
+    P.ownedTiles = total > P.tileRank ? (total - P.tileRank + P.tileWorld - 1) / P.tileWorld : 0;
+    return P;
+}
+
+// Per partition one allocation: control words, two job buffers, the deep stack levels of the walk kernel.
+int ensureWavefront(rt_ctx* ctx, const DevLaunch& L, int parts)
+{
+    const size_t key[6] = { (size_t)ctx->width, (size_t)ctx->height, (size_t)parts, (size_t)L.tileSize,
+                            (size_t)L.tileWorld * 65536 + (size_t)L.tileRank, (size_t)ctx->wavesPerCU * 64 + (size_t)ctx->wfWalkWaves };
+    if (ctx->wfMem[0] && std::memcmp(key, ctx->wfKey, sizeof(key)) == 0) return RT_OK;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < rt_ctx::kMaxParts; ++k)
+        if (ctx->wfStream[k]) RT_HIP(ctx, hipStreamSynchronize(ctx->wfStream[k]));
     freeWavefront(ctx);
-    // a round's list holds at most one entry per pixel, plus one partly used block of 256 entries
-    // per resident wave and list
-    const size_t listCap = ((slots + (size_t)std::max(1, ctx->computeUnits) * 32 * 256 + 63) / 64) * 64;
-    if (slots == 0 || listCap > 0x7fffffffULL) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large for the wavefront pipeline");
-    const size_t ctlBytes = 4096;
-    static_assert((RT_WF_MAX_ROUNDS + 2) * RT_WF_WORDS_PER_ROUND * sizeof(uint32_t) <= 4096, "control block");
-    const size_t jobBytes = (size_t)RT_WF_JOB_ARRAYS * listCap * 16;
-    RT_HIP(ctx, hipMalloc(&ctx->wfMem, ctlBytes + 2 * jobBytes));
-    char* base = static_cast<char*>(ctx->wfMem);
-    ctx->wf.counts = reinterpret_cast<uint32_t*>(base);
-    ctx->wf.jobs[0] = base + ctlBytes;
-    ctx->wf.jobs[1] = base + ctlBytes + jobBytes;
-    ctx->wf.listCap = (int32_t)listCap;
-    ctx->wfSlots = slots;
+    const size_t cus = (size_t)std::max(1, ctx->computeUnits);
+    for (int k = 0; k < parts; ++k) {
+        const DevLaunch P = partLaunch(L, k, parts);
+        // a round's list holds at most one entry per pixel of the partition, plus one partly used
+        // block of 256 entries per wave of the path kernel's grid
+        const size_t pixels = (size_t)P.ownedTiles * (size_t)L.tileSize * (size_t)L.tileSize;
+        const size_t listCap = ((pixels + cus * (size_t)ctx->wavesPerCU * 256 + 63) / 64) * 64 + 64;
+        if (listCap > 0x7fffffffULL) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large for the wavefront pipeline");
+        const size_t ctlBytes = 4096;
+        static_assert((RT_WF_MAX_ROUNDS + 2) * RT_WF_WORDS_PER_ROUND * sizeof(uint32_t) <= 4096, "control block");
+        const size_t jobBytes = (size_t)RT_WF_JOB_ARRAYS * listCap * 16;
+        // deep traversal-stack levels of the walk kernel: (32 - 12) levels x 64 lanes x 8 bytes per wave
+        const size_t deepBytes = cus * (size_t)std::max(1, std::min(32, ctx->wfWalkWaves)) * (RT_MAX_STACK - 12) * 64 * 8;
+        RT_HIP(ctx, hipMalloc(&ctx->wfMem[k], ctlBytes + 2 * jobBytes + deepBytes));
+        char* base = static_cast<char*>(ctx->wfMem[k]);
+        ctx->wf[k].counts = reinterpret_cast<uint32_t*>(base);
+        ctx->wf[k].jobs[0] = base + ctlBytes;
+        ctx->wf[k].jobs[1] = base + ctlBytes + jobBytes;
+        ctx->wf[k].deepStack = base + ctlBytes + 2 * jobBytes;
+        ctx->wf[k].listCap = (int32_t)listCap;
+        if (parts > 1 && !ctx->wfStream[k]) {
+            RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->wfStream[k], hipStreamNonBlocking));
+            RT_HIP(ctx, hipEventCreateWithFlags(&ctx->wfJoin[k], hipEventDisableTiming));
+        }
+    }
+    if (parts > 1 && !ctx->wfFork) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->wfFork, hipEventDisableTiming));
+    std::memcpy(ctx->wfKey, key, sizeof(key));
     return RT_OK;
 }
 
-int launchWavefront(rt_ctx* ctx, const rt_push_constants& pc, const DevLaunch& L, bool statsOnly, bool countBuild)
+// fork / join: the partitions' streams wait for the context's stream before the first frame of a
+// call and the context's stream waits for them after the last, so that between the two the chains of
+// different partitions (and of consecutive frames) overlap freely; they touch disjoint pixels.
+int launchWavefront(rt_ctx* ctx, const rt_push_constants& pc, const DevLaunch& L, bool statsOnly, bool countBuild, bool fork, bool join)
 {
-    int rc = ensureWavefront(ctx);
+    const int parts = std::max(1, std::min(rt_ctx::kMaxParts, ctx->wfParts));
+    int rc = ensureWavefront(ctx, L, parts);
     if (rc != RT_OK) return rc;
-    DevWavefront W = ctx->wf;
-    W.refillMin = std::max(1, std::min(64, ctx->wfRefill));
     const int rounds = std::max(0, std::min(RT_WF_MAX_ROUNDS, ctx->wfRounds));
-    RT_HIP(ctx, hipMemsetAsync(W.counts, 0, 4096, ctx->stream));
     auto path = ctx->optFast ? rt_launch_wf_path_fast : rt_launch_wf_path_strict;
     auto walk = ctx->optFast ? rt_launch_wf_walk_fast : rt_launch_wf_walk_strict;
-    const long long tileWaves = (long long)L.ownedTiles * (L.tileSize / 8) * (L.tileSize / 8);
-    if (tileWaves > 0x7fffffffLL) return fail(ctx, RT_ERR_UNSUPPORTED, "too many tiles");
     const int resident = std::max(1, ctx->computeUnits) * ctx->wavesPerCU;
+    const int walkers = std::max(1, ctx->computeUnits) * std::max(1, std::min(32, ctx->wfWalkWaves));
     DevCounters* cnt = statsOnly ? ctx->dCounters : nullptr;
-    hipError_t e = path(&ctx->scene, &pc, &L, &W, ctx->accum, ctx->draw, cnt, countBuild ? 1 : 0, statsOnly ? 1 : 0, 0,
-                        rounds == 0 ? 1 : 0, (int)std::min<long long>(tileWaves, resident), ctx->stream);
-    for (int r = 0; r < rounds && e == hipSuccess; ++r) {
-        e = walk(&ctx->scene, &pc, &W, countBuild ? 1 : 0, r, resident, ctx->stream);
-        if (e != hipSuccess) break;
-        e = path(&ctx->scene, &pc, &L, &W, ctx->accum, ctx->draw, cnt, countBuild ? 1 : 0, statsOnly ? 1 : 0, r + 1,
-                 r + 1 == rounds ? 1 : 0, resident, ctx->stream);
+    if (parts > 1 && fork) RT_HIP(ctx, hipEventRecord(ctx->wfFork, ctx->stream));
+    for (int k = 0; k < parts; ++k) {
+        const DevLaunch P = partLaunch(L, k, parts);
+        hipStream_t stream = parts > 1 ? ctx->wfStream[k] : ctx->stream;
+        if (parts > 1 && fork) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->wfFork, 0));
+        DevWavefront W = ctx->wf[k];
+        W.refillMin = std::max(1, std::min(64, ctx->wfRefill));
+        RT_HIP(ctx, hipMemsetAsync(W.counts, 0, 4096, stream));
+        const long long tileWaves = (long long)P.ownedTiles * (P.tileSize / 8) * (P.tileSize / 8);
+        if (tileWaves > 0x7fffffffLL) return fail(ctx, RT_ERR_UNSUPPORTED, "too many tiles");
+        hipError_t e = path(&ctx->scene, &pc, &P, &W, ctx->accum, ctx->draw, cnt, countBuild ? 1 : 0, statsOnly ? 1 : 0, 0,
+                            rounds == 0 ? 1 : 0, (int)std::min<long long>(tileWaves, resident), stream);
+        for (int r = 0; r < rounds && e == hipSuccess; ++r) {
+            e = walk(&ctx->scene, &pc, &W, countBuild ? 1 : 0, r, walkers, stream);
+            if (e != hipSuccess) break;
+            e = path(&ctx->scene, &pc, &P, &W, ctx->accum, ctx->draw, cnt, countBuild ? 1 : 0, statsOnly ? 1 : 0, r + 1,
+                     r + 1 == rounds ? 1 : 0, resident, stream);
+        }
+        if (e != hipSuccess) return failHip(ctx, e, "kernel launch");
+        if (parts > 1 && join) {
+            RT_HIP(ctx, hipEventRecord(ctx->wfJoin[k], stream));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->wfJoin[k], 0));
+        }
     }
-    if (e != hipSuccess) return failHip(ctx, e, "kernel launch");
     return RT_OK;
 }
 
-int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsigned long long* diag = nullptr)
+int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsigned long long* diag = nullptr, bool first = true, bool last = true)
 {
     const DevLaunch L = makeLaunch(ctx);
     const bool countBuild = statsOnly || pc.renderMode == 3 || pc.renderMode == 4;
     const bool pathTrace = pc.renderMode == 0 || pc.renderMode == 3 || pc.renderMode == 4;
     hipError_t e;
     if (ctx->optPipeline == 2 && pathTrace && pc.raysPerPixel >= 1 && ctx->scene.objectCount < 65535)   // object indices are packed in 16 bits
-        return launchWavefront(ctx, pc, L, statsOnly, countBuild);
+        return launchWavefront(ctx, pc, L, statsOnly, countBuild, first, last);
     if (ctx->optPipeline == 1 && pathTrace && pc.raysPerPixel >= 1) {
         // persistent grid: enough 64-lane blocks to fill every CU; lanes pull pixels from a counter
         const long long wavesNeeded = ((long long)L.ownedTiles * L.tileSize * L.tileSize + 63) / 64;
@@ -458,6 +506,11 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     freeScene(c);
     freeImages(c);
+    for (int k = 0; k < rt_ctx::kMaxParts; ++k) {
+        if (c->wfStream[k]) { (void)hipStreamSynchronize(c->wfStream[k]); (void)hipStreamDestroy(c->wfStream[k]); }
+        if (c->wfJoin[k]) (void)hipEventDestroy(c->wfJoin[k]);
+    }
+    if (c->wfFork) (void)hipEventDestroy(c->wfFork);
     freeWavefront(c);
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->dQueue) (void)hipFree(c->dQueue);
@@ -499,6 +552,14 @@ int rt_set_option(rt_ctx* ctx, int option, int value)
         if (value < 0 || value > RT_WF_MAX_ROUNDS) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront rounds must be in [0,30]");
         ctx->wfRounds = value;
         return RT_OK;
+    case RT_OPT_WF_WALK_WAVES:
+        if (value < 1 || value > 32) return fail(ctx, RT_ERR_INVALID_ARG, "walk waves per CU must be in [1,32]");
+        ctx->wfWalkWaves = value;
+        return RT_OK;
+    case RT_OPT_WF_PARTS:
+        if (value < 1 || value > rt_ctx::kMaxParts) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront partitions must be in [1,8]");
+        ctx->wfParts = value;
+        return RT_OK;
     case RT_OPT_WF_REFILL:
         if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront refill threshold must be in [1,64]");
         ctx->wfRefill = value;
@@ -528,6 +589,8 @@ int rt_get_option(rt_ctx* ctx, int option, int* value)
     case RT_OPT_WAVES_PER_CU: *value = ctx->wavesPerCU; return RT_OK;
     case RT_OPT_WF_ROUNDS: *value = ctx->wfRounds; return RT_OK;
     case RT_OPT_WF_REFILL: *value = ctx->wfRefill; return RT_OK;
+    case RT_OPT_WF_WALK_WAVES: *value = ctx->wfWalkWaves; return RT_OK;
+    case RT_OPT_WF_PARTS: *value = ctx->wfParts; return RT_OK;
     case RT_OPT_TILE_RANK: *value = ctx->tileRank; return RT_OK;
     case RT_OPT_TILE_WORLD: *value = ctx->tileWorld; return RT_OK;
     case RT_OPT_TILE_SIZE: *value = ctx->tileSize; return RT_OK;
@@ -683,7 +746,7 @@ int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, 
     rt_push_constants p = *pc;
     for (int k = 0; k < count; ++k) {
         p.frame = first_frame + k * stride;
-        if ((rc = launchFrame(ctx, p, false)) != RT_OK) return rc;
+        if ((rc = launchFrame(ctx, p, false, nullptr, k == 0, k == count - 1)) != RT_OK) return rc;
     }
     RT_HIP(ctx, hipEventRecord(ctx->evStop, ctx->stream));
     ctx->timed = true;

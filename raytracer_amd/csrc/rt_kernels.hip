@@ -262,11 +262,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct NodeVisit { bool okF, okS; float EF, ES; int2 refs; };
 
 template <bool PAR>
+__device__ __forceinline__ void node_boxes_loaded(float4 a, float4 b, float4 c, int2 refs, V3 o, V3 inv, float tMin, NodeVisit& r);
+
+template <bool PAR>
 __device__ __forceinline__ void node_boxes(const DevNode* node, V3 o, V3 inv, float tMin, NodeVisit& r)
 {
     const float4* np = reinterpret_cast<const float4*>(node);
     const float4 a = np[0], b = np[1], c = np[2];
-    r.refs = *reinterpret_cast<const int2*>(np + 3);
+    node_boxes_loaded<PAR>(a, b, c, *reinterpret_cast<const int2*>(np + 3), o, inv, tMin, r);
+}
+
+template <bool PAR>
+__device__ __forceinline__ void node_boxes_loaded(float4 a, float4 b, float4 c, int2 refs, V3 o, V3 inv, float tMin, NodeVisit& r)
+{
+    r.refs = refs;
     const f32x2 lox = { a.x, a.y }, loy = { a.z, a.w }, loz = { b.x, b.y };
     const f32x2 hix = { b.z, b.w }, hiy = { c.x, c.y }, hiz = { c.z, c.w };
     const f32x2 ox = { o.x, o.x }, oy = { o.y, o.y }, oz = { o.z, o.z };
@@ -791,10 +800,16 @@ struct LaneTrace {
 
 // One triangle: IntersectTriangle (raytrace.comp:278-328) plus the acceptance test of
 // raytrace.comp:559-572. Returns true when the hit was accepted.
+__device__ __forceinline__ bool lane_triangle_loaded(LaneTrace& t, const float* fwd, float4 t0, float4 t1, float4 t2, float tMin, int& remaining);
+
 __device__ __forceinline__ bool lane_triangle(const DevScene& S, LaneTrace& t, const float* fwd, int triIndex, float tMin, int& remaining)
 {
     const float4* tp = reinterpret_cast<const float4*>(S.tris + triIndex);
-    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+    return lane_triangle_loaded(t, fwd, tp[0], tp[1], tp[2], tMin, remaining);
+}
+
+__device__ __forceinline__ bool lane_triangle_loaded(LaneTrace& t, const float* fwd, float4 t0, float4 t1, float4 t2, float tMin, int& remaining)
+{
     remaining = __float_as_int(t0.w);
     V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
     V3 h = cross3(t.ld, e2);
@@ -1370,6 +1385,20 @@ __device__ __forceinline__ void wf_close(WaveBlock& blk, float4* holes, float4 h
     blk.left = 0;
 }
 
+// Job records stream through the chip once per round; they are written and read with the
+// non-temporal hint so that they do not push the scene out of the L2.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 wf_load(const float4* p)
+{
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void wf_store(float4* p, float4 v)
+{
+    const f32x4 x = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p));
+}
+
 __device__ __forceinline__ float4* wf_job(const DevWavefront& W, int parity, int part)
 {
     return reinterpret_cast<float4*>(W.jobs[parity]) + (size_t)part * (size_t)W.listCap;
@@ -1396,19 +1425,19 @@ __device__ __forceinline__ void wf_emit(const DevWavefront& W, int round, WaveBl
     const unsigned idx = wf_append(blk, &W.counts[round * RT_WF_WORDS_PER_ROUND + 0], wf_job(W, par, 0), wf_job_hole(), m);
     if (emit) {
         const uint32_t meta = (uint32_t)obj | (shadow ? 0x80000000u : 0u);
-        wf_job(W, par, 0)[idx] = make_float4(org.x, org.y, org.z, __int_as_float(slot));
-        wf_job(W, par, 1)[idx] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(meta));
-        wf_job(W, par, 2)[idx] = make_float4(best.closest, best.tLocal, best.u, best.v);
-        wf_job(W, par, 3)[idx] = make_float4(__int_as_float(best.object + 1), __int_as_float(best.tri),
-                                             __int_as_float(cnt.nodeTests), __int_as_float(cnt.triTests));
-        wf_job(W, par, 4)[idx] = make_float4(v.throughput.x, v.throughput.y, v.throughput.z, __int_as_float(v.sample));
-        wf_job(W, par, 5)[idx] = make_float4(v.result.x, v.result.y, v.result.z, __int_as_float(v.bounce));
+        wf_store(wf_job(W, par, 0) + idx, make_float4(org.x, org.y, org.z, __int_as_float(slot)));
+        wf_store(wf_job(W, par, 1) + idx, make_float4(dir.x, dir.y, dir.z, __uint_as_float(meta)));
+        wf_store(wf_job(W, par, 2) + idx, make_float4(best.closest, best.tLocal, best.u, best.v));
+        wf_store(wf_job(W, par, 3) + idx, make_float4(__int_as_float(best.object + 1), __int_as_float(best.tri),
+                                             __int_as_float(cnt.nodeTests), __int_as_float(cnt.triTests)));
+        wf_store(wf_job(W, par, 4) + idx, make_float4(v.throughput.x, v.throughput.y, v.throughput.z, __int_as_float(v.sample)));
+        wf_store(wf_job(W, par, 5) + idx, make_float4(v.result.x, v.result.y, v.result.z, __int_as_float(v.bounce)));
         if (shadow) {
-            wf_job(W, par, 6)[idx] = make_float4(v.pendD.x, v.pendD.y, v.pendD.z, 0.0f);
-            wf_job(W, par, 7)[idx] = make_float4(v.pendO.x, v.pendO.y, v.pendO.z, 0.0f);
-            wf_job(W, par, 8)[idx] = make_float4(v.pendDir.x, v.pendDir.y, v.pendDir.z, 0.0f);
+            wf_store(wf_job(W, par, 6) + idx, make_float4(v.pendD.x, v.pendD.y, v.pendD.z, 0.0f));
+            wf_store(wf_job(W, par, 7) + idx, make_float4(v.pendO.x, v.pendO.y, v.pendO.z, 0.0f));
+            wf_store(wf_job(W, par, 8) + idx, make_float4(v.pendDir.x, v.pendDir.y, v.pendDir.z, 0.0f));
         }
-        if (wide) wf_job(W, par, 9)[idx] = make_float4(v.nc.x, v.nc.y, v.nc.z, __int_as_float(cnt.rays));
+        if (wide) wf_store(wf_job(W, par, 9) + idx, make_float4(v.nc.x, v.nc.y, v.nc.z, __int_as_float(cnt.rays)));
     }
 }
 
@@ -1500,12 +1529,12 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_con
         } else {
             const unsigned job = chunk * 64u + (unsigned)lane;
             float4 a = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-            if (job < jobsIn) a = wf_job(W, prev, 0)[job];
+            if (job < jobsIn) a = wf_load(wf_job(W, prev, 0) + job);
             slot = __float_as_int(a.w);
             alive = slot >= 0;   // -1: unused entry of a writer's block
             if (alive) {
-                float4 b = wf_job(W, prev, 1)[job], r0 = wf_job(W, prev, 2)[job], r1 = wf_job(W, prev, 3)[job];
-                float4 e = wf_job(W, prev, 4)[job], f = wf_job(W, prev, 5)[job];
+                float4 b = wf_load(wf_job(W, prev, 1) + job), r0 = wf_load(wf_job(W, prev, 2) + job), r1 = wf_load(wf_job(W, prev, 3) + job);
+                float4 e = wf_load(wf_job(W, prev, 4) + job), f = wf_load(wf_job(W, prev, 5) + job);
                 kind = (__float_as_uint(b.w) & 0x80000000u) ? 2 : 1;
                 py = slot / L.width; px = slot - py * L.width;
                 best.closest = r0.x; best.tLocal = r0.y; best.u = r0.z; best.v = r0.w;
@@ -1516,14 +1545,14 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_con
                 v.result = mk(f.x, f.y, f.z); v.bounce = __float_as_int(f.w);
                 seed = seed_from_coords((uint32_t)px, (uint32_t)py, (uint32_t)pc.frame, (uint32_t)v.sample);
                 if (kind == 2) {
-                    float4 g = wf_job(W, prev, 6)[job], h = wf_job(W, prev, 7)[job], k = wf_job(W, prev, 8)[job];
+                    float4 g = wf_load(wf_job(W, prev, 6) + job), h = wf_load(wf_job(W, prev, 7) + job), k = wf_load(wf_job(W, prev, 8) + job);
                     v.pendD = mk(g.x, g.y, g.z); v.pendO = mk(h.x, h.y, h.z); v.pendDir = mk(k.x, k.y, k.z);
                     resumeO = mk(a.x, a.y, a.z);
                 } else {
                     v.rayO = mk(a.x, a.y, a.z); v.rayD = mk(b.x, b.y, b.z);
                 }
                 if (wide) {
-                    float4 j = wf_job(W, prev, 9)[job];
+                    float4 j = wf_load(wf_job(W, prev, 9) + job);
                     v.nc = mk(j.x, j.y, j.z); cnt.rays = __float_as_int(j.w);
                 }
             }
@@ -1676,6 +1705,26 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_con
     }
 }
 
+// The walk kernel keeps only the first RT_WF_LDS_LEVELS levels of a lane's traversal stack in LDS
+// (deeper entries are rare) and the rest in a per-wave region of HBM, so that twice as many waves
+// fit on a compute unit and hide each other's record fetches.
+#define RT_WF_LDS_LEVELS 12
+__device__ __forceinline__ void wf_push(LaneTrace& t, uint2* lds, uint2* deep, uint2 e)
+{
+    if (t.sp < RT_WF_LDS_LEVELS) lds[t.sp * 64] = e; else deep[(t.sp - RT_WF_LDS_LEVELS) * 64] = e;
+    ++t.sp;
+}
+// Next stack entry whose box still reaches inside the closest hit, or RT_NONE.
+__device__ __forceinline__ int wf_pop(LaneTrace& t, const uint2* lds, const uint2* deep)
+{
+    while (t.sp > 0) {
+        --t.sp;
+        const uint2 e = t.sp < RT_WF_LDS_LEVELS ? lds[t.sp * 64] : deep[(t.sp - RT_WF_LDS_LEVELS) * 64];
+        if (t.closest > __uint_as_float(e.y)) return (int)e.x;
+    }
+    return RT_NONE;
+}
+
 #define RT_WF_BOX 0x7ffffffd   /* LaneTrace::cur: at the parent box of object `obj` */
 
 // Persistent grid. Lane states: 0 free, 1 walking, 2 finished (result still in registers), 3 retired.
@@ -1685,6 +1734,7 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
     extern __shared__ uint2 stackMem[];
     const int lane = threadIdx.x;
     uint2* stack = stackMem + lane;
+    uint2* deep = reinterpret_cast<uint2*>(W.deepStack) + (size_t)blockIdx.x * (RT_MAX_STACK - RT_WF_LDS_LEVELS) * 64 + lane;
     const int parentCount = pc.parentBVHCount;
     const float tMin = 0.001f;
     const bool permute = !COUNT && parentCount == S.objectCount;
@@ -1708,9 +1758,9 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
         if (walking == 0 || (!exhausted && walking <= 64 - refillMin)) {
             // hand finished rays on: the answer goes back into parts 2 and 3 of the job's own record
             if (st == 2) {
-                wf_job(W, par, 2)[job] = make_float4(t.closest, t.bestT, t.bestU, t.bestV);
-                wf_job(W, par, 3)[job] = make_float4(__int_as_float((t.bestObj + 1) | (t.obj << 16)), __int_as_float(t.bestTri),
-                                                     __int_as_float(cNode), __int_as_float(cTri));
+                wf_store(wf_job(W, par, 2) + job, make_float4(t.closest, t.bestT, t.bestU, t.bestV));
+                wf_store(wf_job(W, par, 3) + job, make_float4(__int_as_float((t.bestObj + 1) | (t.obj << 16)), __int_as_float(t.bestTri),
+                                                     __int_as_float(cNode), __int_as_float(cTri)));
                 st = 0;
             }
             // take new jobs from the list, of which this wave reserves 256 entries at a time
@@ -1729,9 +1779,9 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
                 if (st == 0 && idx >= jobs) st = 3;
                 exhausted = __any(st == 3);
                 if (st == 0) {
-                    float4 a = wf_job(W, par, 0)[idx], b = wf_job(W, par, 1)[idx];
+                    float4 a = wf_load(wf_job(W, par, 0) + idx), b = wf_load(wf_job(W, par, 1) + idx);
                     if (__float_as_int(a.w) >= 0) {   // else an unused entry of a writer's block
-                        float4 c = wf_job(W, par, 2)[idx], d = wf_job(W, par, 3)[idx];
+                        float4 c = wf_load(wf_job(W, par, 2) + idx), d = wf_load(wf_job(W, par, 3) + idx);
                         const uint32_t meta = __float_as_uint(b.w);
                         job = (int)idx;
                         t.rayO = mk(a.x, a.y, a.z);
@@ -1772,25 +1822,30 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
 
         if (st == 1) {
             int next = t.cur;
-            if (t.cur == RT_WF_BOX) {
+            // Whatever the lane is at - a parent (DevObject), a two-child record (DevNode) or a
+            // triangle (DevTri) - the first 64 bytes of that record are fetched here, before the
+            // three kinds of step part ways, so an iteration waits for memory once, not three times.
+            const bool atBox = t.cur == RT_WF_BOX;
+            const bool atEnd = atBox && t.obj >= parentCount;
+            const float4* rec = atBox ? reinterpret_cast<const float4*>(S.objects + (atEnd ? 0 : t.obj))
+                                      : (t.cur >= 0 ? reinterpret_cast<const float4*>(S.nodes + t.cur)
+                                                    : reinterpret_cast<const float4*>(S.tris + ~t.cur));
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+            if (atBox) {
                 // next parent, raytrace.comp:458-486: a BVH parent is walked here, at anything else
                 // the ray goes back to the path kernel, which continues the object loop there
-                int root = -1;
-                float4 b0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                const float4* op = reinterpret_cast<const float4*>(S.objects + (t.obj < parentCount ? t.obj : 0));
-                if (t.obj < parentCount) { b0 = op[0]; root = __float_as_int(b0.w); }
+                const int root = atEnd ? -1 : __float_as_int(r0.w);
                 if (root < 0) {
                     st = 2;
                 } else {
-                    float4 b1 = op[1];
                     if (COUNT) cNode++;
-                    V3 bmn = mk(b0.x, b0.y, b0.z), bmx = mk(b1.x, b1.y, b1.z);
+                    V3 bmn = mk(r0.x, r0.y, r0.z), bmx = mk(r1.x, r1.y, r1.z);
                     float E;
                     bool ok = (__any(flags & F_PAR_WORLD) ? lean_box<true>(t.rayO, winv, bmn, bmx, tMin, E)
                                                           : lean_box<false>(t.rayO, winv, bmn, bmx, tMin, E)) && (t.closest > E);
                     if (ok) ok = !(distance_to_aabb(t.rayO, bmn, bmx) > t.closest);
                     if (ok) {
-                        float4 i0 = op[2], i1 = op[3], i2 = op[4];
+                        const float4 i0 = r2, i1 = r3, i2 = rec[4];
                         t.lo = mk((i0.x * t.rayO.x + i0.y * t.rayO.y) + (i0.z * t.rayO.z + i0.w * 1.0f),
                                   (i1.x * t.rayO.x + i1.y * t.rayO.y) + (i1.z * t.rayO.z + i1.w * 1.0f),
                                   (i2.x * t.rayO.x + i2.y * t.rayO.y) + (i2.z * t.rayO.z + i2.w * 1.0f));
@@ -1806,7 +1861,9 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
                 }
             } else if (t.cur >= 0) {
                 NodeVisit nv;
-                visit_node(S, t.cur, t.lo, t.linv, __any(flags & F_PAR_LOCAL), tMin, nv);
+                const int2 recRefs = make_int2(__float_as_int(r3.x), __float_as_int(r3.y));
+                if (__any(flags & F_PAR_LOCAL)) node_boxes_loaded<true>(r0, r1, r2, recRefs, t.lo, t.linv, tMin, nv);
+                else node_boxes_loaded<false>(r0, r1, r2, recRefs, t.lo, t.linv, tMin, nv);
                 const int2 refs = nv.refs;
                 const float EF = nv.EF, ES = nv.ES;
                 const bool okF = nv.okF, okS = nv.okS;
@@ -1814,19 +1871,19 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
                 const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (t.closest > EF);
                 const bool canS = refs.y > RT_REF_LIVE_MIN && okS;
                 if (goF) {
-                    if (canS) { stack[t.sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(ES)); ++t.sp; }
+                    if (canS) wf_push(t, stack, deep, make_uint2((uint32_t)refs.y, __float_as_uint(ES)));
                     next = refs.x;
                 } else if (canS && (t.closest > ES)) {
                     next = refs.y;
                 } else {
-                    next = lane_pop(t, stack);
+                    next = wf_pop(t, stack, deep);
                 }
             } else {
                 int remaining;
                 if (COUNT) cTri++;
-                const bool hit = lane_triangle(S, t, S.objects[t.obj].fwd, ~t.cur, tMin, remaining);
+                const bool hit = lane_triangle_loaded(t, S.objects[t.obj].fwd, r0, r1, r2, tMin, remaining);
                 if (!COUNT && hit && (flags & F_SHADOW)) { st = 2; t.obj = parentCount; }   // any hit settles a shadow ray
-                else if (remaining <= 1) next = lane_pop(t, stack);
+                else if (remaining <= 1) next = wf_pop(t, stack, deep);
                 else next = t.cur - 1;   // ~(k+1)
             }
             if (next == RT_NONE) {   // this object is done: on to the next parent
@@ -1934,7 +1991,7 @@ extern "C" hipError_t RT_SYM(rt_launch_wf_walk)(const DevScene* S, const rt_push
                                                 int countBuild, int round, int blocks, hipStream_t stream)
 {
     if (blocks <= 0) return hipSuccess;
-    const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
+    const size_t lds = (size_t)(S->stackDepth < RT_WF_LDS_LEVELS ? S->stackDepth : RT_WF_LDS_LEVELS) * 64 * sizeof(uint2);
     dim3 grid((unsigned)blocks), block(64);
     if (countBuild)
         hipLaunchKernelGGL(RT_SYM(rt_wf_walk)<true>, grid, block, lds, stream, *S, *pc, *W, round);
