@@ -321,6 +321,38 @@ struct Best {
 
 struct HitRec { V3 point, normal; int matIndex; float t; bool frontFace; bool hit; };
 
+// IntersectTriangle (raytrace.comp:278-328) on one DevTri record, followed by the acceptance test
+// GetHit applies to its result (raytrace.comp:559-572): the hit must lie inside (tMin, closest) both
+// as the object-space hitT and as the world-space distance. lo / ld: the ray in the object's space;
+// fwd: rows 0-2 of inverse(inverseTransform). Returns true, with `best` updated, when accepted.
+__device__ __forceinline__ bool triangle_hit(float4 t0, float4 t1, float4 t2, V3 lo, V3 ld, const float* fwd, V3 org, V3 dirN,
+                                             float tMin, int objectIndex, Best& best)
+{
+    V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
+    V3 h = cross3(ld, e2);
+    float det = dot3(e1, h);
+    const float eps = 1e-5f;
+    if (fabsf(det) < eps) return false;
+    float invDet = 1.0f / det;
+    V3 s = lo - v0;
+    float u = invDet * dot3(s, h);
+    V3 sc = cross3(s, e1);
+    float v = invDet * dot3(ld, sc);
+    bool miss = (u < -eps || u > 1.0f + eps) || (v < -eps || u + v > 1.0f + eps);
+    float hitT = invDet * dot3(e2, sc);
+    if (miss || !(hitT >= tMin && hitT <= best.closest) || !(hitT > eps)) return false;
+    V3 p = lo + ld * hitT;
+    V3 wp = xform(fwd, p, 1.0f);
+    float worldT = dot3(wp - org, dirN);
+    if (!(worldT > tMin && worldT < best.closest)) return false;
+    best.closest = worldT;
+    best.tLocal = hitT;
+    best.u = u; best.v = v;
+    best.object = objectIndex;
+    best.tri = __float_as_int(t1.w);
+    return true;
+}
+
 #define RT_NONE 0x7fffffff
 
 // GetHit, raytrace.comp:448-610. dirN must already be normalize(r_in.direction).
@@ -395,33 +427,8 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
                     float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                     const int remaining = __float_as_int(t0.w);
                     if (COUNT) cnt.triTests++;
-                    // IntersectTriangle, raytrace.comp:278-328
-                    V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
-                    V3 h = cross3(ld, e2);
-                    float det = dot3(e1, h);
-                    const float eps = 1e-5f;
-                    if (!(fabsf(det) < eps)) {
-                        float invDet = 1.0f / det;
-                        V3 s = lo - v0;
-                        float u = invDet * dot3(s, h);
-                        V3 sc = cross3(s, e1);
-                        float v = invDet * dot3(ld, sc);
-                        bool miss = (u < -eps || u > 1.0f + eps) || (v < -eps || u + v > 1.0f + eps);
-                        float hitT = invDet * dot3(e2, sc);
-                        if (!miss && (hitT >= tMin && hitT <= best.closest) && hitT > eps) {
-                            // raytrace.comp:559-572
-                            V3 p = lo + ld * hitT;
-                            V3 wp = xform(ob->fwd, p, 1.0f);
-                            float worldT = dot3(wp - org, dirN);
-                            if (worldT > tMin && worldT < best.closest) {
-                                best.closest = worldT;
-                                best.tLocal = hitT;
-                                best.u = u; best.v = v;
-                                best.object = i;
-                                best.tri = __float_as_int(t1.w);
-                                if (ANYHIT) return true;
-                            }
-                        }
+                    if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, i, best)) {
+                        if (ANYHIT) return true;
                     }
                     if (remaining <= 1) break;
                     ++k;
@@ -791,10 +798,9 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_megakernel)(DevScene S, rt_push_
 struct LaneTrace {
     V3 rayO, dirN;      // world ray (dirN normalised)
     V3 lo, ld, linv;    // ray in the space of object `obj`, reciprocal direction (NaN = parallel axis)
-    float closest, bestT, bestU, bestV;
-    int bestObj, bestTri;
+    Best best;          // closest hit so far
     int obj;            // index in the parent array
-    int cur;            // K_TRAV: >= 0 two-child record, < 0 leaf triangle ~cur
+    int cur;            // inside a walk: >= 0 two-child record, < 0 leaf triangle ~cur
     int sp;
 };
 
@@ -811,38 +817,7 @@ __device__ __forceinline__ bool lane_triangle(const DevScene& S, LaneTrace& t, c
 __device__ __forceinline__ bool lane_triangle_loaded(LaneTrace& t, const float* fwd, float4 t0, float4 t1, float4 t2, float tMin, int& remaining)
 {
     remaining = __float_as_int(t0.w);
-    V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
-    V3 h = cross3(t.ld, e2);
-    float det = dot3(e1, h);
-    const float eps = 1e-5f;
-    bool accepted = false;
-    if (!(fabsf(det) < eps)) {
-        float invDet = 1.0f / det;
-        V3 s = t.lo - v0;
-        float u = invDet * dot3(s, h);
-        V3 sc = cross3(s, e1);
-        float v = invDet * dot3(t.ld, sc);
-        bool miss = (u < -eps || u > 1.0f + eps) || (v < -eps || u + v > 1.0f + eps);
-        float hitT = invDet * dot3(e2, sc);
-        if (!miss && (hitT >= tMin && hitT <= t.closest) && hitT > eps) {
-            const float4* fp = reinterpret_cast<const float4*>(fwd);
-            float4 f0 = fp[0], f1 = fp[1], f2 = fp[2];
-            V3 p = t.lo + t.ld * hitT;
-            V3 wp = mk((f0.x * p.x + f0.y * p.y) + (f0.z * p.z + f0.w * 1.0f),
-                       (f1.x * p.x + f1.y * p.y) + (f1.z * p.z + f1.w * 1.0f),
-                       (f2.x * p.x + f2.y * p.y) + (f2.z * p.z + f2.w * 1.0f));
-            float worldT = dot3(wp - t.rayO, t.dirN);
-            if (worldT > tMin && worldT < t.closest) {
-                t.closest = worldT;
-                t.bestT = hitT;
-                t.bestU = u; t.bestV = v;
-                t.bestObj = t.obj;
-                t.bestTri = __float_as_int(t1.w);
-                accepted = true;
-            }
-        }
-    }
-    return accepted;
+    return triangle_hit(t0, t1, t2, t.lo, t.ld, fwd, t.rayO, t.dirN, tMin, t.obj, t.best);
 }
 
 // Next stack entry whose box still reaches inside the closest hit, or RT_NONE.
@@ -851,7 +826,7 @@ __device__ __forceinline__ int lane_pop(LaneTrace& t, const uint2* stack)
     while (t.sp > 0) {
         --t.sp;
         uint2 e = stack[t.sp * 64];
-        if (t.closest > __uint_as_float(e.y)) return (int)e.x;
+        if (t.best.closest > __uint_as_float(e.y)) return (int)e.x;
     }
     return RT_NONE;
 }
@@ -894,7 +869,7 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
     V3 pendO = mk(0.0f, 0.0f, 0.0f), pendDir = rayD;   // scattered ray waiting behind the shadow ray
     LaneTrace t;
     t.rayO = mk(0.0f, 0.0f, 0.0f); t.dirN = rayD; t.lo = t.rayO; t.ld = rayD; t.linv = winv;
-    t.closest = 1e20f; t.bestT = t.bestU = t.bestV = 0.0f; t.bestObj = -1; t.bestTri = 0;
+    t.best.closest = 1e20f; t.best.tLocal = t.best.u = t.best.v = 0.0f; t.best.object = -1; t.best.tri = 0;
     t.obj = parentCount;                      // "trace complete": the first shade stage fetches a pixel
     t.cur = RT_ENTER; t.sp = 0;
     int cRays = 0, cNode = 0, cTri = 0;
@@ -939,12 +914,12 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
                         const float EF = nv.EF, ES = nv.ES;
                         const bool okF = nv.okF, okS = nv.okS;
                         if (COUNT) cNode += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
-                        const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (t.closest > EF);
+                        const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (t.best.closest > EF);
                         const bool canS = refs.y > RT_REF_LIVE_MIN && okS;
                         if (goF) {
                             if (canS) { stack[t.sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(ES)); ++t.sp; }
                             next = refs.x;
-                        } else if (canS && (t.closest > ES)) {
+                        } else if (canS && (t.best.closest > ES)) {
                             next = refs.y;
                         } else {
                             next = lane_pop(t, stack);
@@ -977,17 +952,14 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
                     int startTrace = 0;
                     if (flags & F_SHADOW) {
                         // back from ShadowTransmission, raytrace.comp:733-753
-                        if (t.bestObj < 0) result = result + pendD;
+                        if (t.best.object < 0) result = result + pendD;
                         flags &= ~F_SHADOW;
                         t.rayO = pendO; rayD = pendDir;
                         ++bounce;
                         if (bounce < bounces) startTrace = 1; else pathEnd = 1;
                     } else {
-                        Best best;
-                        best.closest = t.closest; best.tLocal = t.bestT; best.u = t.bestU; best.v = t.bestV;
-                        best.object = t.bestObj; best.tri = t.bestTri;
                         HitRec rec;
-                        finish_hit(S, t.rayO, t.dirN, best, rec);
+                        finish_hit(S, t.rayO, t.dirN, t.best, rec);
                         if (!rec.hit) {
                             result = result + throughput * environment_colour(pc, rayD);
                             pathEnd = 1;
@@ -1104,8 +1076,8 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
                     // start of GetHit for the ray just made, raytrace.comp:450-456
                     t.dirN = normalize3(rayD);
                     flags = lean_inverse(t.dirN, winv) ? (flags | F_PAR_WORLD) : (flags & ~F_PAR_WORLD);
-                    t.closest = 1e20f;
-                    t.bestObj = -1;
+                    t.best.closest = 1e20f;
+                    t.best.object = -1;
                     t.obj = (permute && (flags & F_SHADOW)) ? S.anyFirst : 0;
                     if (COUNT) cRays++;
                 }
@@ -1126,8 +1098,8 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
                     V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
                     float E;
                     bool ok = ((flags & F_PAR_WORLD) ? lean_box<true>(t.rayO, winv, bmn, bmx, tMin, E)
-                                                     : lean_box<false>(t.rayO, winv, bmn, bmx, tMin, E)) && (t.closest > E);
-                    if (ok) ok = !(distance_to_aabb(t.rayO, bmn, bmx) > t.closest);
+                                                     : lean_box<false>(t.rayO, winv, bmn, bmx, tMin, E)) && (t.best.closest > E);
+                    if (ok) ok = !(distance_to_aabb(t.rayO, bmn, bmx) > t.best.closest);
                     ok = ok && root > RT_REF_LIVE_MIN;
                     if (!ok) {
                         t.obj = nextObj;
@@ -1233,31 +1205,8 @@ __device__ __forceinline__ bool walk_in_place(const DevScene& S, const DevObject
                 float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                 const int remaining = __float_as_int(t0.w);
                 if (COUNT) cnt.triTests++;
-                V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
-                V3 h = cross3(ld, e2);
-                float det = dot3(e1, h);
-                const float eps = 1e-5f;
-                if (!(fabsf(det) < eps)) {
-                    float invDet = 1.0f / det;
-                    V3 s = lo - v0;
-                    float u = invDet * dot3(s, h);
-                    V3 sc = cross3(s, e1);
-                    float v = invDet * dot3(ld, sc);
-                    bool miss = (u < -eps || u > 1.0f + eps) || (v < -eps || u + v > 1.0f + eps);
-                    float hitT = invDet * dot3(e2, sc);
-                    if (!miss && (hitT >= tMin && hitT <= best.closest) && hitT > eps) {
-                        V3 p = lo + ld * hitT;
-                        V3 wp = xform(ob->fwd, p, 1.0f);
-                        float worldT = dot3(wp - org, dirN);
-                        if (worldT > tMin && worldT < best.closest) {
-                            best.closest = worldT;
-                            best.tLocal = hitT;
-                            best.u = u; best.v = v;
-                            best.object = objIndex;
-                            best.tri = __float_as_int(t1.w);
-                            if (early) return true;
-                        }
-                    }
+                if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, objIndex, best)) {
+                    if (early) return true;
                 }
                 if (remaining <= 1) break;
                 ++k;
@@ -1321,31 +1270,8 @@ __device__ __forceinline__ int trace_until_walk(const DevScene& S, int parentCou
             float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
             const int remaining = __float_as_int(t0.w);
             if (COUNT) cnt.triTests++;
-            V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
-            V3 h = cross3(ld, e2);
-            float det = dot3(e1, h);
-            const float eps = 1e-5f;
-            if (!(fabsf(det) < eps)) {
-                float invDet = 1.0f / det;
-                V3 s = lo - v0;
-                float u = invDet * dot3(s, h);
-                V3 sc = cross3(s, e1);
-                float v = invDet * dot3(ld, sc);
-                bool miss = (u < -eps || u > 1.0f + eps) || (v < -eps || u + v > 1.0f + eps);
-                float hitT = invDet * dot3(e2, sc);
-                if (!miss && (hitT >= tMin && hitT <= best.closest) && hitT > eps) {
-                    V3 p = lo + ld * hitT;
-                    V3 wp = xform(ob->fwd, p, 1.0f);
-                    float worldT = dot3(wp - org, dirN);
-                    if (worldT > tMin && worldT < best.closest) {
-                        best.closest = worldT;
-                        best.tLocal = hitT;
-                        best.u = u; best.v = v;
-                        best.object = i;
-                        best.tri = __float_as_int(t1.w);
-                        if (early) { next = parentCount; break; }
-                    }
-                }
+            if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, i, best)) {
+                if (early) { next = parentCount; break; }
             }
             if (remaining <= 1) break;
             ++k;
@@ -1720,7 +1646,7 @@ __device__ __forceinline__ int wf_pop(LaneTrace& t, const uint2* lds, const uint
     while (t.sp > 0) {
         --t.sp;
         const uint2 e = t.sp < RT_WF_LDS_LEVELS ? lds[t.sp * 64] : deep[(t.sp - RT_WF_LDS_LEVELS) * 64];
-        if (t.closest > __uint_as_float(e.y)) return (int)e.x;
+        if (t.best.closest > __uint_as_float(e.y)) return (int)e.x;
     }
     return RT_NONE;
 }
@@ -1748,7 +1674,7 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
     V3 winv = mk(1.0f, 1.0f, 1.0f);
     LaneTrace t;
     t.rayO = mk(0.0f, 0.0f, 0.0f); t.dirN = mk(0.0f, 0.0f, 1.0f); t.lo = t.rayO; t.ld = t.dirN; t.linv = winv;
-    t.closest = 1e20f; t.bestT = t.bestU = t.bestV = 0.0f; t.bestObj = -1; t.bestTri = 0;
+    t.best.closest = 1e20f; t.best.tLocal = t.best.u = t.best.v = 0.0f; t.best.object = -1; t.best.tri = 0;
     t.obj = 0; t.cur = RT_WF_BOX; t.sp = 0;
     bool exhausted = false;   // wave-uniform: the list has no more entries
     unsigned inNext = 0, inLeft = 0;   // this wave's range of the job list
@@ -1758,8 +1684,8 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
         if (walking == 0 || (!exhausted && walking <= 64 - refillMin)) {
             // hand finished rays on: the answer goes back into parts 2 and 3 of the job's own record
             if (st == 2) {
-                wf_store(wf_job(W, par, 2) + job, make_float4(t.closest, t.bestT, t.bestU, t.bestV));
-                wf_store(wf_job(W, par, 3) + job, make_float4(__int_as_float((t.bestObj + 1) | (t.obj << 16)), __int_as_float(t.bestTri),
+                wf_store(wf_job(W, par, 2) + job, make_float4(t.best.closest, t.best.tLocal, t.best.u, t.best.v));
+                wf_store(wf_job(W, par, 3) + job, make_float4(__int_as_float((t.best.object + 1) | (t.obj << 16)), __int_as_float(t.best.tri),
                                                      __int_as_float(cNode), __int_as_float(cTri)));
                 st = 0;
             }
@@ -1788,8 +1714,8 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
                         t.dirN = normalize3(mk(b.x, b.y, b.z));
                         flags = (meta & 0x80000000u) ? F_SHADOW : 0;
                         if (lean_inverse(t.dirN, winv)) flags |= F_PAR_WORLD;
-                        t.closest = c.x; t.bestT = c.y; t.bestU = c.z; t.bestV = c.w;
-                        t.bestObj = __float_as_int(d.x) - 1; t.bestTri = __float_as_int(d.y);
+                        t.best.closest = c.x; t.best.tLocal = c.y; t.best.u = c.z; t.best.v = c.w;
+                        t.best.object = __float_as_int(d.x) - 1; t.best.tri = __float_as_int(d.y);
                         cNode = __float_as_int(d.z); cTri = __float_as_int(d.w);
                         t.obj = (int)(meta & 0x3fffffffu);
                         st = 2;   // a GetHit call that was already complete passes straight through
@@ -1842,8 +1768,8 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
                     V3 bmn = mk(r0.x, r0.y, r0.z), bmx = mk(r1.x, r1.y, r1.z);
                     float E;
                     bool ok = (__any(flags & F_PAR_WORLD) ? lean_box<true>(t.rayO, winv, bmn, bmx, tMin, E)
-                                                          : lean_box<false>(t.rayO, winv, bmn, bmx, tMin, E)) && (t.closest > E);
-                    if (ok) ok = !(distance_to_aabb(t.rayO, bmn, bmx) > t.closest);
+                                                          : lean_box<false>(t.rayO, winv, bmn, bmx, tMin, E)) && (t.best.closest > E);
+                    if (ok) ok = !(distance_to_aabb(t.rayO, bmn, bmx) > t.best.closest);
                     if (ok) {
                         const float4 i0 = r2, i1 = r3, i2 = rec[4];
                         t.lo = mk((i0.x * t.rayO.x + i0.y * t.rayO.y) + (i0.z * t.rayO.z + i0.w * 1.0f),
@@ -1868,12 +1794,12 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
                 const float EF = nv.EF, ES = nv.ES;
                 const bool okF = nv.okF, okS = nv.okS;
                 if (COUNT) cNode += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
-                const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (t.closest > EF);
+                const bool goF = refs.x > RT_REF_LIVE_MIN && okF && (t.best.closest > EF);
                 const bool canS = refs.y > RT_REF_LIVE_MIN && okS;
                 if (goF) {
                     if (canS) wf_push(t, stack, deep, make_uint2((uint32_t)refs.y, __float_as_uint(ES)));
                     next = refs.x;
-                } else if (canS && (t.closest > ES)) {
+                } else if (canS && (t.best.closest > ES)) {
                     next = refs.y;
                 } else {
                     next = wf_pop(t, stack, deep);
