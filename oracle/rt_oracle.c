@@ -57,6 +57,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "../include/rt_math.h"   /* exp / exp2 / log2 / acos in fixed binary32 arithmetic, shared with the kernels */
+
 /* ------------------------------------------------------------------------- */
 /* data contract (own copies of the layouts; RaytracerTypes.h:22-149)         */
 /* ------------------------------------------------------------------------- */
@@ -118,7 +120,7 @@ static inline float fmin_glsl(float a, float b) { return b < a ? b : a; }
 static inline float clamp_glsl(float x, float lo, float hi) { return fmin_glsl(fmax_glsl(x, lo), hi); }
 static inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 static inline v3 vmix(v3 a, v3 b, float t) { return V(mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t)); }
-static inline float pow_glsl(float x, float y) { return exp2f(y * log2f(x)); }
+static inline float pow_glsl(float x, float y) { return rt_exp2f(y * rt_log2f(x)); }
 static inline v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
 static inline float comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
@@ -302,6 +304,13 @@ void orc_sample_square(uint32_t seed, float out2[2])
 {
     v3 o = sample_square(&seed);
     out2[0] = o.x; out2[1] = o.y;
+}
+
+/* rt_math.h functions over an array (which: 0 exp2, 1 exp, 2 log2, 3 acos), for the accuracy tests */
+void orc_math_apply(int which, const float* x, float* y, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        y[i] = which == 0 ? rt_exp2f(x[i]) : which == 1 ? rt_expf(x[i]) : which == 2 ? rt_log2f(x[i]) : rt_acosf(x[i]);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -503,7 +512,7 @@ static float reflectance(float cosine, float refIdx)
 static void dielectric_scatter(const orc_material* m, const ray_t* rayIn, const hit_t* rec, float refIdx,
                                v3* attenuation, ray_t* scattered, uint32_t seed)
 {
-    v3 e = V(expf(-m->absorbtion[0] * rec->t), expf(-m->absorbtion[1] * rec->t), expf(-m->absorbtion[2] * rec->t));
+    v3 e = V(rt_expf(-m->absorbtion[0] * rec->t), rt_expf(-m->absorbtion[1] * rec->t), rt_expf(-m->absorbtion[2] * rec->t));
     *attenuation = vmul(ld3(m->colour), e);
     float etai = rec->frontFace ? (1.0f / refIdx) : refIdx;
     v3 unit = vnormalize(rayIn->direction);
@@ -569,7 +578,7 @@ static v3 environment_colour(const orc_pc* pc, const ray_t* ray)
     float cosTheta = vdot(unitDir, vneg(sunDir));
     cosTheta = clamp_glsl(cosTheta, 0.0f, 1.0f);
     const float halfDegree = 0.5f * 0.017453292519943295f; /* radians(0.5) */
-    float sunDisk = expf(-pow_glsl(acosf(cosTheta) / halfDegree, 2.0f));
+    float sunDisk = rt_expf(-pow_glsl(rt_acosf(cosTheta) / halfDegree, 2.0f));
     v3 sunGlow = vscale(vscale(ld3(pc->sunColour), pc->sunStrength), sunDisk);
     return vadd(baseSky, sunGlow);
 }

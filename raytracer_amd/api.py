@@ -147,6 +147,7 @@ def load_library():
         "rt_rgba32f_to_rgba8": (None, [vp, vp, C.c_size_t]),
         "rt_write_png_rgba8": (ci, [C.c_char_p, vp, ci, ci]), "rt_save_png": (ci, [vp, C.c_char_p]),
         "rt_produce_render": (ci, [vp, P(PushConstants), ci, C.c_char_p, P(C.c_double)]),
+        "rt_math_apply": (ci, [vp, ci, vp, vp, C.c_size_t]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol
@@ -164,7 +165,7 @@ EXPORTED_SYMBOLS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_last_error", "rt_scene_add_material", "rt_scene_material_index",
     "rt_scene_load_model", "rt_scene_add_object", "rt_scene_set_object", "rt_scene_set_material", "rt_scene_buffer_data",
     "rt_scene_get_buffers", "rt_scene_init_default", "rt_scene_model_info", "rt_rgba32f_to_rgba8", "rt_write_png_rgba8",
-    "rt_save_png", "rt_produce_render"]
+    "rt_save_png", "rt_produce_render", "rt_math_apply"]
 
 
 def _f3(v):
@@ -363,6 +364,13 @@ class Renderer:
         self._check(self.lib.rt_produce_render(self.h, C.byref(pc), int(render_frames),
                                                str(png_path).encode() if png_path is not None else None, C.byref(sec)))
         return sec.value
+
+    def math_apply(self, which, x):
+        """The device's rt_math.h functions over an array: which = 'exp2' | 'exp' | 'log2' | 'acos'."""
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x)
+        self._check(self.lib.rt_math_apply(self.h, {"exp2": 0, "exp": 1, "log2": 2, "acos": 3}[which], x.ctypes.data, y.ctypes.data, x.size))
+        return y
 
     def last_render_ms(self):
         a, b = C.c_float(), C.c_float()

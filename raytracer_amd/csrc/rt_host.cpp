@@ -42,6 +42,8 @@ hipError_t rt_launch_wf_path_fast(const DevScene*, const rt_push_constants*, con
                                   DevCounters*, int, int, int, int, int, hipStream_t);
 hipError_t rt_launch_wf_walk_strict(const DevScene*, const rt_push_constants*, const DevWavefront*, int, int, int, hipStream_t);
 hipError_t rt_launch_wf_walk_fast(const DevScene*, const rt_push_constants*, const DevWavefront*, int, int, int, hipStream_t);
+hipError_t rt_launch_math_strict(int, const float*, float*, size_t, hipStream_t);
+hipError_t rt_launch_math_fast(int, const float*, float*, size_t, hipStream_t);
 hipError_t rt_launch_resolve_strict(const void*, void*, size_t, float, hipStream_t);
 hipError_t rt_launch_resolve_fast(const void*, void*, size_t, float, hipStream_t);
 }
@@ -888,6 +890,24 @@ int rt_produce_render(rt_ctx* ctx, rt_push_constants* pc, int render_frames, con
     int rc = png_path ? rt_save_png(ctx, png_path) : rt_sync(ctx);
     if (rc != RT_OK) return rc;
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::system_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_math_apply(rt_ctx* ctx, int which, const float* x, float* y, size_t n)
+{
+    if (!ctx || (n && (!x || !y)) || which < 0 || which > 3) return fail(ctx, RT_ERR_INVALID_ARG, "rt_math_apply: bad argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    float *dx = nullptr, *dy = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&dx, n * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&dy, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = (ctx->optFast ? rt_launch_math_fast : rt_launch_math_strict)(which, dx, dy, n, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(y, dy, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    if (e != hipSuccess) return failHip(ctx, e, "rt_math_apply");
     return RT_OK;
 }
 

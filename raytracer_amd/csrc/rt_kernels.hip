@@ -30,6 +30,7 @@
 #include <stdint.h>
 
 #include "../../include/rt_types.h"
+#include "../../include/rt_math.h"
 #include "rt_device.h"
 
 #if defined(RT_FLAVOUR_FAST)
@@ -61,7 +62,9 @@ __device__ __forceinline__ float gmin(float a, float b) { return b < a ? b : a; 
 __device__ __forceinline__ float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
 __device__ __forceinline__ float gmix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 __device__ __forceinline__ V3 gmix3(V3 a, V3 b, float t) { return mk(gmix(a.x, b.x, t), gmix(a.y, b.y, t), gmix(a.z, b.z, t)); }
-__device__ __forceinline__ float gpow(float x, float y) { return exp2f(y * log2f(x)); }
+// GLSL pow as exp2(y * log2(x)); the three transcendental functions the shader uses come from
+// rt_math.h, whose results do not depend on the machine's math library.
+__device__ __forceinline__ float gpow(float x, float y) { return rt_exp2f(y * rt_log2f(x)); }
 __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 
 // ---- Random.glsl ----------------------------------------------------------
@@ -515,7 +518,7 @@ __device__ __forceinline__ V3 environment_colour(const rt_push_constants& pc, V3
     }
     float cosTheta = gclamp(dot3(unitDir, -sunDir), 0.0f, 1.0f);
     const float halfDegree = 0.5f * 0.017453292519943295f;
-    float sunDisk = expf(-gpow(acosf(cosTheta) / halfDegree, 2.0f));
+    float sunDisk = rt_expf(-gpow(rt_acosf(cosTheta) / halfDegree, 2.0f));
     V3 sunGlow = (ld3(pc.sunColour) * pc.sunIntensity) * sunDisk;
     return baseSky + sunGlow;
 }
@@ -569,7 +572,7 @@ __device__ __forceinline__ void material_scatter(const DevMaterial& m, V3 rayDir
     if (m.refractionIndex > 0.0f) {
         float refIdx = m.refractionIndex;
         V3 ab = ld3(m.absorbtion);
-        V3 e = mk(expf(-ab.x * rec.t), expf(-ab.y * rec.t), expf(-ab.z * rec.t));
+        V3 e = mk(rt_expf(-ab.x * rec.t), rt_expf(-ab.y * rec.t), rt_expf(-ab.z * rec.t));
         attenuation = ld3(m.colour) * e;
         float etai = rec.frontFace ? (1.0f / refIdx) : refIdx;
         V3 unit = normalize3(rayDir);
@@ -1834,6 +1837,16 @@ __global__ __launch_bounds__(256) void RT_SYM(rt_resolve_kernel)(const float4* _
     }
 }
 
+// rt_math.h over an array (which: 0 exp2, 1 exp, 2 log2, 3 acos): lets a test compare the device's
+// results with the host's bit for bit.
+__global__ __launch_bounds__(256) void RT_SYM(rt_math_kernel)(int which, const float* __restrict__ x, float* __restrict__ y, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        y[i] = which == 0 ? rt_exp2f(x[i]) : which == 1 ? rt_expf(x[i]) : which == 2 ? rt_log2f(x[i]) : rt_acosf(x[i]);
+}
+
 // ---- launchers (called from rt_host.cpp) ---------------------------------------
 
 extern "C" hipError_t RT_SYM(rt_launch_megakernel)(const DevScene* S, const rt_push_constants* pc, const DevLaunch* L,
@@ -1923,5 +1936,14 @@ extern "C" hipError_t RT_SYM(rt_launch_wf_walk)(const DevScene* S, const rt_push
         hipLaunchKernelGGL(RT_SYM(rt_wf_walk)<true>, grid, block, lds, stream, *S, *pc, *W, round);
     else
         hipLaunchKernelGGL(RT_SYM(rt_wf_walk)<false>, grid, block, lds, stream, *S, *pc, *W, round);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t RT_SYM(rt_launch_math)(int which, const float* x, float* y, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(RT_SYM(rt_math_kernel), dim3((unsigned)blocks), dim3(256), 0, stream, which, x, y, n);
     return hipGetLastError();
 }

@@ -27,6 +27,7 @@ def lib():
         L.orc_rng_draw.restype = C.c_uint32
         L.orc_rng_draw.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
         L.orc_sample_square.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
+        L.orc_math_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_scene_new.restype = C.c_void_p
         L.orc_scene_free.argtypes = [C.c_void_p]
         L.orc_load_model.argtypes = [C.c_void_p, C.c_char_p]
@@ -56,6 +57,14 @@ def rng_draw(state):
     m = C.c_uint32()
     s = lib().orc_rng_draw(state, C.byref(m))
     return s, m.value
+
+
+def math_apply(which, x):
+    """include/rt_math.h over an array: which = 'exp2' | 'exp' | 'log2' | 'acos'."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().orc_math_apply({'exp2': 0, 'exp': 1, 'log2': 2, 'acos': 3}[which], x.ctypes.data, y.ctypes.data, x.size)
+    return y
 
 
 def sample_square(seed):

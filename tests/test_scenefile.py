@@ -123,14 +123,8 @@ def test_generated_scenes_bit_exact_on_gpu(tmp_path, pipeline):
                 r.render_frame(pc)
                 o = O.render(arrays, pc.as_bytes(), W, H, accum=acc_o, counters=True); acc_o = o["accum"]
             acc = r.read_image(R.RT_IMAGE_ACCUM); out = r.read_image(R.RT_IMAGE_DRAW)
-            # open sky and glass put exp / acos / pow into the colours, where device and host libm
-            # may differ in the last bit: colours within 1e-5 (relative + absolute) on >= 99.9 % of
-            # the pixels, bit-equal on >= 97 %; the work counters have no such input and are exact
-            equal = np.all(acc.view(np.uint32) == acc_o.view(np.uint32), axis=2).mean()
-            close = closeness(acc, acc_o)
-            assert equal >= 0.97 and close >= 0.999, (desc["name"], equal, close)
-            close = closeness(out, o["out"])
-            assert close >= 0.999, (desc["name"], close)
+            assert np.array_equal(acc.view(np.uint32), acc_o.view(np.uint32)), desc["name"]
+            assert np.array_equal(out.view(np.uint32), o["out"].view(np.uint32)), desc["name"]
             st = r.frame_stats(pc)
             assert (st.rays, st.bvhNodeTests, st.triangleTests) == (int(o["rays"].sum()), int(o["node"].sum()), int(o["tri"].sum()))
             # the depth view has no transcendental in it: bit-exact
