@@ -43,6 +43,8 @@
  *   mix(a,b,t) = a*(1-t)+b*t;  reflect(I,N) = I - (2*dot(N,I))*N
  *   refract: k = 1-eta*eta*(1-d*d), k<0 ? 0 : eta*I-(eta*d+sqrt(k))*N
  *   pow(x,y) = exp2(y*log2(x))  (NaN for x<0, as GPU drivers and Mesa lower it)
+ *   exp, exp2, log2, acos = the fixed-arithmetic versions of include/rt_math.h (<= 4 ulp), not the
+ *   host libm's, so that the kernels - which compile the same header - agree in the last bit
  *   max(a,b) = a<b?b:a;  min(a,b) = b<a?b:a;  mat4*vec4 = (c0*x+c1*y)+(c2*z+c3*w)
  *   inverse(mat4) = glm's cofactor form
  */
