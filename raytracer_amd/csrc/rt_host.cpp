@@ -89,7 +89,7 @@ struct rt_ctx {
     hipStream_t wfStream[kMaxParts] = {};
     hipEvent_t wfFork = nullptr, wfJoin[kMaxParts] = {};
     size_t wfKey[6] = {};
-    int wfRounds = 5, wfRefill = 16, wfWalkWaves = 12, wfParts = 3;
+    int wfRounds = 5, wfRefill = 16, wfWalkWaves = 12, wfParts = 1;
 
     int optFast = 0, optPipeline = 0, tileRank = 0, tileWorld = 1, tileSize = 64;
     std::string error;

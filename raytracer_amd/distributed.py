@@ -79,11 +79,16 @@ class GpuTarget:
         self.r = renderer
         self.pc = push_constants
         self.device = torch.device(device)
+        # A stream of its own, made torch's current stream: rt_set_stream(NULL) means "the context's
+        # own stream", so the legacy default stream (handle 0) cannot be handed to the library.
+        self._previous = torch.cuda.current_stream(self.device)
+        self.stream = torch.cuda.Stream(self.device)
+        torch.cuda.set_stream(self.stream)
         self.draw = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
         self.accum = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
         torch.cuda.synchronize(self.device)
         renderer.bind_images(self.draw.data_ptr(), self.accum.data_ptr(), width, height)
-        renderer.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        renderer.set_stream(self.stream.cuda_stream)
 
     def clear(self):
         self.draw.zero_()
@@ -101,5 +106,7 @@ class GpuTarget:
         self.r.resolve(total_frames)
 
     def close(self):
+        torch.cuda.synchronize(self.device)
         self.r.set_stream(None)
         self.r.bind_images(None, None, 0, 0)
+        torch.cuda.set_stream(self._previous)

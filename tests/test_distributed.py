@@ -115,3 +115,66 @@ def test_two_rank_gloo_sample_and_tile_split(tmp_path, default_scene_arrays):
         out = np.load(tmp_path / ("ts_out_%d.npy" % rank))
         assert np.array_equal(got.view(np.uint32), acc.view(np.uint32))
         assert np.array_equal(out.view(np.uint32), r["out"].view(np.uint32))
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    """Two processes that share cuda:0 (a rehearsal: RCCL wants one GPU per rank, so the collective
+    goes over gloo here; the drivers and the kernels are the ones an 8-GPU run uses)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import raytracer_amd as R
+    Wg, Hg = 160, 96
+    s = R.Scene(); s.init_default()
+    r = R.Renderer(0)
+    r.upload_scene(s.buffers())
+    pc = R.default_push_constants(); R.camera_to_push_constants(R.default_camera(), Wg, Hg, pc); pc.parentBVHCount = 8
+    for pipeline in (0, 2):
+        r.set_option(R.RT_OPT_PIPELINE, pipeline)
+        tgt = D.GpuTarget(r, pc, Wg, Hg, "cuda:0")
+        total = D.render_sample_split(tgt, frames_per_rank=2)
+        assert total == 2 * world
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "g_ss_acc_%d_%d.npy" % (pipeline, rank)), tgt.accum.cpu().numpy())
+        np.save(os.path.join(out_dir, "g_ss_out_%d_%d.npy" % (pipeline, rank)), tgt.draw.cpu().numpy())
+        D.render_tile_split(tgt, frames=2, tile_size=32)
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "g_ts_acc_%d_%d.npy" % (pipeline, rank)), tgt.accum.cpu().numpy())
+        np.save(os.path.join(out_dir, "g_ts_out_%d_%d.npy" % (pipeline, rank)), tgt.draw.cpu().numpy())
+        tgt.close()
+    r.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_sample_and_tile_split(tmp_path):
+    import raytracer_amd as R
+    world, Wg, Hg = 2, 160, 96
+    mp.spawn(_gpu_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    s = R.Scene(); s.init_default()
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(s.buffers()); r.resize(Wg, Hg)
+        pc = R.default_push_constants(); R.camera_to_push_constants(R.default_camera(), Wg, Hg, pc); pc.parentBVHCount = 8
+        # what each rank accumulates on its own: frames r, r+2
+        parts = []
+        for rank in range(world):
+            r.clear_accumulation()
+            r.render_frames(pc, rank, world, 2)
+            parts.append(r.read_image(R.RT_IMAGE_ACCUM))
+        merged = parts[0] + parts[1]
+        r.clear_accumulation()
+        r.render_frames(pc, 0, 1, 2)
+        seq_acc, seq_out = r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW)
+    finally:
+        r.close()
+    for pipeline in (0, 2):
+        for rank in range(world):
+            got = np.load(tmp_path / ("g_ss_acc_%d_%d.npy" % (pipeline, rank)))
+            assert np.array_equal(got[..., :3].view(np.uint32), merged[..., :3].view(np.uint32))   # a + b, the same on every rank
+            out = np.load(tmp_path / ("g_ss_out_%d_%d.npy" % (pipeline, rank)))
+            want = np.sqrt(np.maximum(got[..., :3] * np.float32(1.0 / 4), 0), dtype=np.float32)
+            assert np.array_equal(out[..., :3].view(np.uint32), want.view(np.uint32))
+            assert np.array_equal(np.load(tmp_path / ("g_ts_acc_%d_%d.npy" % (pipeline, rank))).view(np.uint32), seq_acc.view(np.uint32))
+            assert np.array_equal(np.load(tmp_path / ("g_ts_out_%d_%d.npy" % (pipeline, rank))).view(np.uint32), seq_out.view(np.uint32))
