@@ -81,7 +81,11 @@ enum {
      * its own stream, so that the thin end of one chain overlaps with the bulk of another (3 is
      * the fastest setting measured; more streams than hardware queues serialise, and two processes
      * that share one GPU should stay at 1). */
-    RT_OPT_WF_ROUNDS = 12, RT_OPT_WF_REFILL = 13, RT_OPT_WF_WALK_WAVES = 14, RT_OPT_WF_PARTS = 15
+    RT_OPT_WF_ROUNDS = 12, RT_OPT_WF_REFILL = 13, RT_OPT_WF_WALK_WAVES = 14, RT_OPT_WF_PARTS = 15,
+    /* Read-only (rt_get_option) facts about the uploaded scene: traversal stack entries a lane can
+     * need (longest chain of two-child records), number of two-child records, and number of
+     * triangle records in leaf order (a triangle that several leaves share counts once per leaf). */
+    RT_INFO_STACK_DEPTH = 100, RT_INFO_RECORDS = 101, RT_INFO_TRIANGLES = 102
 };
 
 /* ---- device context ------------------------------------------------------ */

@@ -66,6 +66,7 @@ struct rt_ctx {
     void* dAnyOrder = nullptr;
     bool haveScene = false;
     size_t sceneBytes = 0;
+    size_t nodeCount = 0, triCount = 0;
 
     // images
     int width = 0, height = 0;
@@ -593,6 +594,9 @@ int rt_get_option(rt_ctx* ctx, int option, int* value)
     case RT_OPT_WF_REFILL: *value = ctx->wfRefill; return RT_OK;
     case RT_OPT_WF_WALK_WAVES: *value = ctx->wfWalkWaves; return RT_OK;
     case RT_OPT_WF_PARTS: *value = ctx->wfParts; return RT_OK;
+    case RT_INFO_STACK_DEPTH: *value = ctx->haveScene ? ctx->scene.stackDepth : 0; return RT_OK;
+    case RT_INFO_RECORDS: *value = ctx->haveScene ? (int)std::min<size_t>(ctx->nodeCount, 0x7fffffff) : 0; return RT_OK;
+    case RT_INFO_TRIANGLES: *value = ctx->haveScene ? (int)std::min<size_t>(ctx->triCount, 0x7fffffff) : 0; return RT_OK;
     case RT_OPT_TILE_RANK: *value = ctx->tileRank; return RT_OK;
     case RT_OPT_TILE_WORLD: *value = ctx->tileWorld; return RT_OK;
     case RT_OPT_TILE_SIZE: *value = ctx->tileSize; return RT_OK;
@@ -683,6 +687,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
     for (int i = 0; i < P; ++i) ctx->scene.anyLeafCount += rl.dObjects[i].root < 0 ? 1 : 0;
     ctx->scene.objectCount = (int32_t)rl.dObjects.size();
     ctx->scene.stackDepth = std::max(1, std::min(RT_MAX_STACK, rl.maxDepth));
+    ctx->nodeCount = rl.dNodes.size();
+    ctx->triCount = rl.dTris.size();
     ctx->sceneBytes = rl.dObjects.size() * sizeof(DevObject) + rl.dNodes.size() * sizeof(DevNode) + rl.dTris.size() * sizeof(DevTri) +
                       nrms.size() * sizeof(DevNrm) + b->materials.count * sizeof(DevMaterial);
     ctx->haveScene = true;
