@@ -208,6 +208,14 @@ int rt_scene_add_object(rt_scene* s, const char* model_path, const float positio
 int rt_scene_set_object(rt_scene* s, int index, const float position[3],
                         const float rotation_deg[3], const float scale[3], int material_index);
 int rt_scene_set_material(rt_scene* s, int index, const rt_gpu_material* m);
+/* What the scene editor reads back (SceneEditorUI.hpp:23-97 walks m_sceneObjects and
+ * m_sceneMaterials): the number of objects / materials and one entry of either list. model_path
+ * may be NULL; otherwise it receives the object's model path (model_path_cap bytes available). */
+int rt_scene_object_count(rt_scene* s);
+int rt_scene_material_count(rt_scene* s);
+int rt_scene_get_object(rt_scene* s, int index, char* model_path, size_t model_path_cap, float position[3],
+                        float rotation_deg[3], float scale[3], int* material_index);
+int rt_scene_get_material(rt_scene* s, int index, rt_gpu_material* out);
 /* BufferSceneData's CPU half (HardwareRenderer.cpp:653-657): run
  * ConvertSceneObjectToGPUObject over every object, rebuilding the parent/object
  * arrays. Must be called before rt_scene_get_buffers. */

@@ -142,6 +142,9 @@ def load_library():
         "rt_scene_load_model": (ci, [vp, C.c_char_p]),
         "rt_scene_add_object": (ci, [vp, C.c_char_p, P(cf), P(cf), P(cf), P(Material)]),
         "rt_scene_set_object": (ci, [vp, ci, P(cf), P(cf), P(cf), ci]), "rt_scene_set_material": (ci, [vp, ci, P(Material)]),
+        "rt_scene_object_count": (ci, [vp]), "rt_scene_material_count": (ci, [vp]),
+        "rt_scene_get_object": (ci, [vp, ci, C.c_char_p, C.c_size_t, P(cf), P(cf), P(cf), P(ci)]),
+        "rt_scene_get_material": (ci, [vp, ci, P(Material)]),
         "rt_scene_buffer_data": (ci, [vp]), "rt_scene_get_buffers": (ci, [vp, P(SceneBuffers)]),
         "rt_scene_init_default": (ci, [vp, C.c_char_p, C.c_char_p]),
         "rt_scene_model_info": (ci, [vp, C.c_char_p, P(ci), P(ci), P(ci), P(ci)]),
@@ -166,7 +169,8 @@ EXPORTED_SYMBOLS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_last_error", "rt_scene_add_material", "rt_scene_material_index",
     "rt_scene_load_model", "rt_scene_add_object", "rt_scene_set_object", "rt_scene_set_material", "rt_scene_buffer_data",
     "rt_scene_get_buffers", "rt_scene_init_default", "rt_scene_model_info", "rt_rgba32f_to_rgba8", "rt_write_png_rgba8",
-    "rt_save_png", "rt_produce_render", "rt_math_apply"]
+    "rt_save_png", "rt_produce_render", "rt_math_apply", "rt_scene_object_count", "rt_scene_material_count",
+    "rt_scene_get_object", "rt_scene_get_material"]
 
 
 def _f3(v):
@@ -258,6 +262,25 @@ class Scene:
 
     def set_object(self, index, position, rotation, scale, material_index):
         self._check(self.lib.rt_scene_set_object(self.h, index, _f3(position), _f3(rotation), _f3(scale), material_index))
+
+    def object_count(self):
+        return self.lib.rt_scene_object_count(self.h)
+
+    def material_count(self):
+        return self.lib.rt_scene_material_count(self.h)
+
+    def get_object(self, index):
+        """-> dict(model, position, rotation, scale, material_index): one entry of m_sceneObjects."""
+        name = C.create_string_buffer(4096)
+        pos, rot, scl, mat = _f3((0, 0, 0)), _f3((0, 0, 0)), _f3((0, 0, 0)), C.c_int(0)
+        self._check(self.lib.rt_scene_get_object(self.h, index, name, len(name), pos, rot, scl, C.byref(mat)))
+        return {"model": name.value.decode(), "position": tuple(pos), "rotation": tuple(rot), "scale": tuple(scl),
+                "material_index": mat.value}
+
+    def get_material(self, index):
+        m = Material()
+        self._check(self.lib.rt_scene_get_material(self.h, index, C.byref(m)))
+        return m
 
     def buffer_scene_data(self):
         self._check(self.lib.rt_scene_buffer_data(self.h))

@@ -673,6 +673,35 @@ int rt_scene_set_object(rt_scene* s, int index, const float position[3], const f
     return RT_OK;
 }
 
+int rt_scene_object_count(rt_scene* s) { return s ? (int)s->objects.size() : 0; }
+int rt_scene_material_count(rt_scene* s) { return s ? (int)s->materials.size() : 0; }
+
+int rt_scene_get_object(rt_scene* s, int index, char* model_path, size_t model_path_cap, float position[3],
+                        float rotation_deg[3], float scale_[3], int* material_index)
+{
+    if (!s || index < 0 || (size_t)index >= s->objects.size())
+        return fail(s, RT_ERR_INVALID_ARG, "rt_scene_get_object: bad index");
+    const SceneObject& o = s->objects[index];
+    if (model_path) {
+        if (o.modelName.size() + 1 > model_path_cap)
+            return fail(s, RT_ERR_INVALID_ARG, "rt_scene_get_object: model path needs " + std::to_string(o.modelName.size() + 1) + " bytes");
+        std::memcpy(model_path, o.modelName.c_str(), o.modelName.size() + 1);
+    }
+    if (position) { position[0] = o.position.x; position[1] = o.position.y; position[2] = o.position.z; }
+    if (rotation_deg) { rotation_deg[0] = o.rotation.x; rotation_deg[1] = o.rotation.y; rotation_deg[2] = o.rotation.z; }
+    if (scale_) { scale_[0] = o.scale.x; scale_[1] = o.scale.y; scale_[2] = o.scale.z; }
+    if (material_index) *material_index = o.materialIndex;
+    return RT_OK;
+}
+
+int rt_scene_get_material(rt_scene* s, int index, rt_gpu_material* out)
+{
+    if (!s || !out || index < 0 || (size_t)index >= s->materials.size())
+        return fail(s, RT_ERR_INVALID_ARG, "rt_scene_get_material: bad index");
+    *out = s->materials[index];
+    return RT_OK;
+}
+
 int rt_scene_buffer_data(rt_scene* s)
 {
     if (!s) return fail(s, RT_ERR_INVALID_ARG, "rt_scene_buffer_data: null scene");

@@ -49,3 +49,72 @@ def test_example_renders_the_same_image_as_the_python_binding(tmp_path, pipeline
         rd.close()
     assert fnv1a(img.tobytes()) == checksum
     assert np.array_equal(decode_png(png), R.rgba32f_to_rgba8(img))
+
+
+# ---- examples/viewer_loop.cpp: the HardwareRenderer-shaped C++ class of include/rt_renderer.hpp ----
+
+VIEWER = os.path.join(ROOT, "examples", "viewer_loop")
+
+
+def parse_steps(stdout):
+    steps = {}
+    for line in stdout.splitlines():
+        w = line.split()
+        if w and w[0] == "step":
+            steps[int(w[1])] = {"frame": int(w[3]), "pos": tuple(float(x) for x in w[5:8]), "dir": tuple(float(x) for x in w[9:12]),
+                                "locked": int(w[13]), "refresh": int(w[15])}
+    return steps
+
+
+def test_camera_controller_known_answers():
+    """CameraController.cpp:11-101 by hand: W is ignored until Escape locks the mouse; locked, W for 0.5 s at speed 16
+    moves 8 along the look direction; a mouse delta of 1.8 at sensitivity 50 over 1 s turns yaw from -90 to 0 degrees
+    (look along +x); D for 0.25 s strafes 4 along cross(look, up) = +z."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    r = subprocess.run([VIEWER, "--camera-only"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    s = parse_steps(r.stdout)
+    assert s[4]["pos"] == (0.0, 1.0, 5.0) and s[4]["locked"] == 0
+    assert s[5]["pos"] == (0.0, 1.0, -3.0) and s[5]["locked"] == 1 and s[5]["dir"] == (0.0, 0.0, -1.0)
+    assert s[6]["dir"] == (1.0, 0.0, 0.0) and s[6]["pos"] == (0.0, 1.0, -3.0)
+    assert s[7]["pos"] == (0.0, 1.0, 1.0) and s[7]["dir"] == (1.0, 0.0, 0.0)
+
+
+@pytest.mark.gpu
+def test_viewer_loop_session_matches_the_python_binding(tmp_path):
+    """The frame counter follows MainLoop / RefreshAccumulation / ProduceRender (HardwareRenderer.cpp:840-848, 921-922,
+    1002-1005, 1039-1043), and the PNG the session writes equals what the Python binding renders for the same camera,
+    size and edited scene."""
+    from test_host import decode_png
+    import raytracer_amd as R
+    png = str(tmp_path / "session.png")
+    r = subprocess.run([VIEWER, MODELS, png], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    s = parse_steps(r.stdout)
+    # three idle frames accumulate; every camera move, the resize and the scene edit restart at frame 0 (+1 after the
+    # step); the render request runs the counter up to SetRenderFrames' 8
+    assert [s[k]["frame"] for k in range(1, 12)] == [1, 2, 3, 4, 1, 1, 1, 1, 2, 3, 8]
+    assert all(s[k]["refresh"] == 0 for k in range(1, 12))
+    assert "size 256 144 objects 8 materials 9" in r.stdout and "Render took" in r.stdout
+    W, H = 256, 144
+    sc = R.Scene(); sc.init_default()
+    m = sc.get_material(1); m.albedo = (C_float3)(0.9, 0.2, 0.2); sc.set_material(1, m)
+    o = sc.get_object(6)
+    p = np.array(o["position"], np.float32); p[1] += np.float32(0.5)
+    sc.set_object(6, tuple(p), o["rotation"], o["scale"], o["material_index"])
+    sc.buffer_scene_data()
+    cam = R.default_camera()
+    cam.cameraPosition = (C_float3)(*s[11]["pos"]); cam.cameraLookDirection = (C_float3)(*s[11]["dir"])
+    rd = R.Renderer(0)
+    try:
+        rd.upload_scene(sc.buffers()); rd.resize(W, H)
+        pc = R.default_push_constants(); R.camera_to_push_constants(cam, W, H, pc); pc.parentBVHCount = 8
+        rd.render_frames(pc, 0, 1, 8)
+        img = rd.read_image(R.RT_IMAGE_DRAW)
+    finally:
+        rd.close()
+    assert np.array_equal(decode_png(png), R.rgba32f_to_rgba8(img))
+
+
+import ctypes
+C_float3 = ctypes.c_float * 3

@@ -156,3 +156,25 @@ def test_png_writer_round_trip(tmp_path, W, H):
     assert np.array_equal(decode_png(path), img)
     with pytest.raises(api.RtError):
         api.write_png_rgba8(str(tmp_path / "no_such_dir" / "x.png"), img)
+
+
+def test_scene_lists_can_be_read_back():
+    """rt_scene_get_object / rt_scene_get_material return what InitializeScene and later edits put in
+    (the scene editor's view of m_sceneObjects / m_sceneMaterials, SceneEditorUI.hpp:23-97)."""
+    import raytracer_amd as R
+    s = R.Scene(); s.init_default()
+    assert s.object_count() == 8 and s.material_count() == 9
+    objs = [s.get_object(i) for i in range(8)]
+    assert sum(o["model"].endswith("flat_quad.obj") for o in objs) == 6
+    assert any(o["model"].endswith("dragon_lowres.obj") for o in objs)
+    assert all(0 <= o["material_index"] < 9 for o in objs)
+    m = s.get_material(0)
+    assert tuple(m.albedo) == (0.5, 0.5, 0.5)            # the ground material comes first (HardwareRenderer.cpp:576-581)
+    s.set_object(3, (1.0, 2.0, 3.0), (10.0, 20.0, 30.0), (2.0, 2.0, 2.0), 4)
+    o = s.get_object(3)
+    assert o["position"] == (1.0, 2.0, 3.0) and o["rotation"] == (10.0, 20.0, 30.0) and o["scale"] == (2.0, 2.0, 2.0)
+    assert o["material_index"] == 4
+    with pytest.raises(R.RtError):
+        s.get_object(8)
+    with pytest.raises(R.RtError):
+        s.get_material(-1)
