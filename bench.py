@@ -100,7 +100,7 @@ def main():
     R.camera_to_push_constants(R.default_camera(), W, H, pc)
     pc.parentBVHCount = 8
     from raytracer_amd import distributed as D
-    target = D.GpuTarget(r, pc, W, H, dev)      # images are torch tensors, kernels run on torch's stream
+    target = D.GpuTarget(r, pc, W, H, dev)      # images are torch tensors, kernels run on a torch stream the target owns
     frames = D.frames_of_rank(rank, world, spp)
 
     # untimed counting pass: GetHit calls and the shader's node/triangle test counters per frame

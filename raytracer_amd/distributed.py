@@ -17,8 +17,12 @@ Both take a `target`: any object with
     render_frames(first_frame, stride, count)
     set_tiles(rank, world, tile_size)
     resolve(total_frames)   draw = gamma(accum / total_frames)
-GpuTarget below is the real one (HIP kernels through the C ABI); tests substitute a CPU one.
+and optionally stream_context(): a context manager under which torch work (the clears, the
+collectives) is ordered with the target's kernels. GpuTarget below is the real one (HIP kernels
+through the C ABI); tests substitute a CPU one.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -43,56 +47,66 @@ def _world(group):
     return 0, 1
 
 
-def render_sample_split(target, frames_per_rank, group=None):
+def _ordered(target):
+    return getattr(target, "stream_context", contextlib.nullcontext)()
+
+
+def render_sample_split(target, frames_per_rank, group=None, always_reduce=False):
     """Every rank ends with the merged accumulation image (frames_per_rank * world samples per
-    pixel) and the resolved draw image. Returns the total number of frames."""
+    pixel) and the resolved draw image. Returns the total number of frames. always_reduce: issue
+    the all-reduce even in a group of one (a no-op on the data; lets one GPU exercise the RCCL path)."""
     rank, world = _world(group)
-    target.set_tiles(0, 1, 64)
-    target.clear()
-    target.render_frames(rank, world, frames_per_rank)
-    if world > 1:
-        dist.all_reduce(target.accum, op=dist.ReduceOp.SUM, group=group)
-    total = frames_per_rank * world
-    target.resolve(total)
+    with _ordered(target):
+        target.set_tiles(0, 1, 64)
+        target.clear()
+        target.render_frames(rank, world, frames_per_rank)
+        if world > 1 or always_reduce:
+            dist.all_reduce(target.accum, op=dist.ReduceOp.SUM, group=group)
+        total = frames_per_rank * world
+        target.resolve(total)
     return total
 
 
-def render_tile_split(target, frames, tile_size=64, group=None):
+def render_tile_split(target, frames, tile_size=64, group=None, always_reduce=False):
     """Every rank renders `frames` accumulated frames of its own tiles; afterwards every rank
     holds the complete accumulation and draw images."""
     rank, world = _world(group)
-    target.set_tiles(rank, world, tile_size)
-    target.clear()
-    target.render_frames(0, 1, frames)
-    if world > 1:
-        dist.all_reduce(target.accum, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(target.draw, op=dist.ReduceOp.SUM, group=group)
-    target.set_tiles(0, 1, tile_size)
+    with _ordered(target):
+        target.set_tiles(rank, world, tile_size)
+        target.clear()
+        target.render_frames(0, 1, frames)
+        if world > 1 or always_reduce:
+            dist.all_reduce(target.accum, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(target.draw, op=dist.ReduceOp.SUM, group=group)
+        target.set_tiles(0, 1, tile_size)
     return frames
 
 
 class GpuTarget:
-    """A Renderer drawing into torch tensors on its GPU, on torch's current stream, so that the
-    collectives torch enqueues are ordered after the kernels without host synchronisation."""
+    """A Renderer drawing into torch tensors on its GPU. The kernels run on a torch stream the
+    target owns; torch work issued under stream_context() (the drivers above do that) goes to the
+    same stream, so clears, kernels and collectives are ordered without host synchronisation.
+    (rt_set_stream(NULL) means "the context's own stream", so torch's default stream, whose handle
+    is 0, cannot be handed to the library: hence a stream of the target's own.)"""
 
     def __init__(self, renderer, push_constants, width, height, device):
         self.r = renderer
         self.pc = push_constants
         self.device = torch.device(device)
-        # A stream of its own, made torch's current stream: rt_set_stream(NULL) means "the context's
-        # own stream", so the legacy default stream (handle 0) cannot be handed to the library.
-        self._previous = torch.cuda.current_stream(self.device)
         self.stream = torch.cuda.Stream(self.device)
-        torch.cuda.set_stream(self.stream)
         self.draw = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
         self.accum = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
         torch.cuda.synchronize(self.device)
         renderer.bind_images(self.draw.data_ptr(), self.accum.data_ptr(), width, height)
         renderer.set_stream(self.stream.cuda_stream)
 
+    def stream_context(self):
+        return torch.cuda.stream(self.stream)
+
     def clear(self):
-        self.draw.zero_()
-        self.accum.zero_()
+        with torch.cuda.stream(self.stream):
+            self.draw.zero_()
+            self.accum.zero_()
 
     def render_frames(self, first_frame, stride, count):
         self.r.render_frames(self.pc, first_frame, stride, count)
@@ -109,4 +123,3 @@ class GpuTarget:
         torch.cuda.synchronize(self.device)
         self.r.set_stream(None)
         self.r.bind_images(None, None, 0, 0)
-        torch.cuda.set_stream(self._previous)

@@ -178,3 +178,50 @@ def test_two_ranks_on_one_gpu_sample_and_tile_split(tmp_path):
             assert np.array_equal(out[..., :3].view(np.uint32), want.view(np.uint32))
             assert np.array_equal(np.load(tmp_path / ("g_ts_acc_%d_%d.npy" % (pipeline, rank))).view(np.uint32), seq_acc.view(np.uint32))
             assert np.array_equal(np.load(tmp_path / ("g_ts_out_%d_%d.npy" % (pipeline, rank))).view(np.uint32), seq_out.view(np.uint32))
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """One rank, backend nccl (= RCCL): the all-reduce of a group of one changes no data, but it goes
+    through RCCL on the target's stream like the all-reduce of an 8-GPU run."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    import raytracer_amd as R
+    Wg, Hg = 160, 96
+    s = R.Scene(); s.init_default()
+    r = R.Renderer(0)
+    r.upload_scene(s.buffers())
+    pc = R.default_push_constants(); R.camera_to_push_constants(R.default_camera(), Wg, Hg, pc); pc.parentBVHCount = 8
+    tgt = D.GpuTarget(r, pc, Wg, Hg, "cuda:0")
+    for k in range(3):   # back to back without host synchronisation: clear / kernels / collective / resolve must stay in order
+        D.render_sample_split(tgt, frames_per_rank=3, always_reduce=True)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, "n_ss_acc.npy"), tgt.accum.cpu().numpy())
+    np.save(os.path.join(out_dir, "n_ss_out.npy"), tgt.draw.cpu().numpy())
+    D.render_tile_split(tgt, frames=3, tile_size=32, always_reduce=True)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, "n_ts_acc.npy"), tgt.accum.cpu().numpy())
+    tgt.close()
+    r.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_all_reduce_on_the_target_stream(tmp_path):
+    import raytracer_amd as R
+    Wg, Hg = 160, 96
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    s = R.Scene(); s.init_default()
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(s.buffers()); r.resize(Wg, Hg)
+        pc = R.default_push_constants(); R.camera_to_push_constants(R.default_camera(), Wg, Hg, pc); pc.parentBVHCount = 8
+        r.render_frames(pc, 0, 1, 3)
+        acc, out = r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW)
+    finally:
+        r.close()
+    assert np.array_equal(np.load(tmp_path / "n_ss_acc.npy").view(np.uint32), acc.view(np.uint32))
+    assert np.array_equal(np.load(tmp_path / "n_ss_out.npy")[..., :3].view(np.uint32), out[..., :3].view(np.uint32))
+    assert np.array_equal(np.load(tmp_path / "n_ts_acc.npy").view(np.uint32), acc.view(np.uint32))
