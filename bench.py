@@ -173,6 +173,18 @@ def main():
                          "valu": {"achieved_tflops": flops_per_launch / (launch_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
                                   "frac": flops_per_launch / (launch_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},
         }
+        if world == 1:
+            # the other reading of "64 spp": ONE dispatch with raysPerPixel = 64 (samples seeded by the
+            # sample index instead of the frame index, raytrace.comp:779-783), after the timed region
+            p64 = pc.copy()
+            p64.raysPerPixel = spp
+            p64.frame = 0
+            target.clear()
+            r.render_frames(p64, 0, 1, 1)
+            r.sync()
+            r.render_frames(p64, 0, 1, 1)
+            r.sync()
+            out["ms_single_dispatch_%dspp" % spp] = r.last_render_ms()[0]
         if world == 1 and args.cpu_seconds > 0:
             threads = min(16, os.cpu_count() or 1)
             p0 = pc.copy()
