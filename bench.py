@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--spp", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--fast", type=int, default=0, help="1 = FMA-contracted flavour (not bit-exact with the oracle)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables it")
+    ap.add_argument("--single-dispatch", type=int, default=0,
+                    help="1 = also time 64 spp as ONE dispatch with raysPerPixel = 64 (extra launches of the same kernel: off by "
+                         "default so that a profile of the default run holds only the timed launches)")
     args = ap.parse_args()
 
     import numpy as np
@@ -145,9 +148,12 @@ def main():
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        launch_ms = float(np.mean(kernel_ms)) / spp           # average duration of one dispatch of the megakernel
-        bytes_per_launch = (40.0 * node + 48.0 * tri + 48.0 * W * H * spp) / spp     # rank 0's frames
-        flops_per_launch = (21.0 * node + 45.0 * tri) / spp
+        # one launch of the megakernel renders `group` consecutive frames (RT_OPT_FRAMES_PER_LAUNCH)
+        group = r.get_option(R.RT_OPT_FRAMES_PER_LAUNCH)
+        launches = (spp + group - 1) // group
+        launch_ms = float(np.mean(kernel_ms)) / launches      # average duration of one launch of the megakernel
+        bytes_per_launch = (40.0 * node + 48.0 * tri + 48.0 * W * H * spp) / launches     # rank 0's frames
+        flops_per_launch = (21.0 * node + 45.0 * tri) / launches
         achieved_gbps = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -169,11 +175,12 @@ def main():
             "rays_per_step": total_rays,
             "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rt_megakernel", "launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernel": "rt_megakernel", "launch_ms": launch_ms, "frames_per_launch": group,
+                         "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "valu": {"achieved_tflops": flops_per_launch / (launch_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
                                   "frac": flops_per_launch / (launch_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},
         }
-        if world == 1:
+        if world == 1 and args.single_dispatch:
             # the other reading of "64 spp": ONE dispatch with raysPerPixel = 64 (samples seeded by the
             # sample index instead of the frame index, raytrace.comp:779-783), after the timed region
             p64 = pc.copy()

@@ -82,6 +82,13 @@ enum {
      * the fastest setting measured; more streams than hardware queues serialise, and two processes
      * that share one GPU should stay at 1). */
     RT_OPT_WF_ROUNDS = 12, RT_OPT_WF_REFILL = 13, RT_OPT_WF_WALK_WAVES = 14, RT_OPT_WF_PARTS = 15,
+    /* Pipeline 0, rt_render_frames in path-tracing mode: this many consecutive frames of the call are
+     * rendered by one kernel launch, every pixel keeping its accumulation value in registers from
+     * one frame to the next - the additions a sequence of single-frame dispatches performs, in the
+     * same order, so both images are the same bit for bit; the draw image is written for the last
+     * frame of a launch only. Saves the launch ramps and draw-image writes. Default 8; 1 = one launch per
+     * frame. rt_render_frame (one frame) is not affected. */
+    RT_OPT_FRAMES_PER_LAUNCH = 16,
     /* Read-only (rt_get_option) facts about the uploaded scene: traversal stack entries a lane can
      * need (longest chain of two-child records), number of two-child records, and number of
      * triangle records in leaf order (a triangle that several leaves share counts once per leaf). */

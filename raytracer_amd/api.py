@@ -17,6 +17,7 @@ RT_IMAGE_DRAW, RT_IMAGE_ACCUM = 0, 1
 RT_OPT_FAST_MATH, RT_OPT_PIPELINE, RT_OPT_TILE_RANK, RT_OPT_TILE_WORLD, RT_OPT_TILE_SIZE, RT_OPT_WAVES_PER_CU = 1, 2, 3, 4, 5, 6
 RT_OPT_SCHED_BIAS_OBJECT, RT_OPT_SCHED_BIAS_TRAV, RT_OPT_SCHED_BIAS_SHADE, RT_OPT_SCHED_QUORUM_MIN, RT_OPT_SCHED_QUORUM_DIV = 7, 8, 9, 10, 11
 RT_OPT_WF_ROUNDS, RT_OPT_WF_REFILL, RT_OPT_WF_WALK_WAVES, RT_OPT_WF_PARTS = 12, 13, 14, 15
+RT_OPT_FRAMES_PER_LAUNCH = 16
 RT_INFO_STACK_DEPTH, RT_INFO_RECORDS, RT_INFO_TRIANGLES = 100, 101, 102
 
 

@@ -93,6 +93,9 @@ struct DevLaunch {
     /* round selection of the wave-scheduled kernel: the kind with the largest (waiting lanes -
      * bias) runs; a BVH round ends when fewer than max(quorumMin, started/quorumDiv) lanes walk */
     int32_t biasObject, biasTrav, biasShade, quorumMin, quorumDiv;
+    /* lock-step kernel, path tracing: consecutive frames rendered by one launch (>= 1) and the step
+     * of the frame index between them */
+    int32_t frames, frameStride;
 };
 
 /* Buffers of the wavefront pipeline. A ray that leaves the path kernel becomes a job: a record

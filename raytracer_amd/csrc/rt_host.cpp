@@ -91,6 +91,7 @@ struct rt_ctx {
     hipEvent_t wfFork = nullptr, wfJoin[kMaxParts] = {};
     size_t wfKey[6] = {};
     int wfRounds = 5, wfRefill = 16, wfWalkWaves = 12, wfParts = 1;
+    int framesPerLaunch = 8;
 
     int optFast = 0, optPipeline = 0, tileRank = 0, tileWorld = 1, tileSize = 64;
     std::string error;
@@ -334,6 +335,8 @@ DevLaunch makeLaunch(const rt_ctx* c)
     L.ownedTiles = total > c->tileRank ? (total - c->tileRank + c->tileWorld - 1) / c->tileWorld : 0;
     L.biasObject = c->policy[0]; L.biasTrav = c->policy[1]; L.biasShade = c->policy[2];
     L.quorumMin = std::max(1, c->policy[3]); L.quorumDiv = std::max(1, c->policy[4]);
+    L.frames = 1;
+    L.frameStride = 1;
     return L;
 }
 
@@ -443,9 +446,12 @@ int launchWavefront(rt_ctx* ctx, const rt_push_constants& pc, const DevLaunch& L
     return RT_OK;
 }
 
-int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsigned long long* diag = nullptr, bool first = true, bool last = true)
+int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsigned long long* diag = nullptr, bool first = true, bool last = true,
+                int frames = 1, int frameStride = 1)
 {
-    const DevLaunch L = makeLaunch(ctx);
+    DevLaunch L = makeLaunch(ctx);
+    L.frames = frames;
+    L.frameStride = frameStride;
     const bool countBuild = statsOnly || pc.renderMode == 3 || pc.renderMode == 4;
     const bool pathTrace = pc.renderMode == 0 || pc.renderMode == 3 || pc.renderMode == 4;
     hipError_t e;
@@ -563,6 +569,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value)
         if (value < 1 || value > rt_ctx::kMaxParts) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront partitions must be in [1,8]");
         ctx->wfParts = value;
         return RT_OK;
+    case RT_OPT_FRAMES_PER_LAUNCH:
+        if (value < 1 || value > 4096) return fail(ctx, RT_ERR_INVALID_ARG, "frames per launch must be in [1,4096]");
+        ctx->framesPerLaunch = value;
+        return RT_OK;
     case RT_OPT_WF_REFILL:
         if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront refill threshold must be in [1,64]");
         ctx->wfRefill = value;
@@ -594,6 +604,7 @@ int rt_get_option(rt_ctx* ctx, int option, int* value)
     case RT_OPT_WF_REFILL: *value = ctx->wfRefill; return RT_OK;
     case RT_OPT_WF_WALK_WAVES: *value = ctx->wfWalkWaves; return RT_OK;
     case RT_OPT_WF_PARTS: *value = ctx->wfParts; return RT_OK;
+    case RT_OPT_FRAMES_PER_LAUNCH: *value = ctx->framesPerLaunch; return RT_OK;
     case RT_INFO_STACK_DEPTH: *value = ctx->haveScene ? ctx->scene.stackDepth : 0; return RT_OK;
     case RT_INFO_RECORDS: *value = ctx->haveScene ? (int)std::min<size_t>(ctx->nodeCount, 0x7fffffff) : 0; return RT_OK;
     case RT_INFO_TRIANGLES: *value = ctx->haveScene ? (int)std::min<size_t>(ctx->triCount, 0x7fffffff) : 0; return RT_OK;
@@ -752,9 +763,14 @@ int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipEventRecord(ctx->evStart, ctx->stream));
     rt_push_constants p = *pc;
-    for (int k = 0; k < count; ++k) {
+    // the lock-step kernel can run several consecutive frames of a pixel in one launch (same
+    // arithmetic in the same order, one read and one write of the accumulation pixel)
+    const bool fuse = ctx->optPipeline == 0 && pc->renderMode == 0 && pc->raysPerPixel >= 1 && ctx->framesPerLaunch > 1;
+    const int group = fuse ? ctx->framesPerLaunch : 1;
+    for (int k = 0; k < count; k += group) {
+        const int n = std::min(group, count - k);
         p.frame = first_frame + k * stride;
-        if ((rc = launchFrame(ctx, p, false, nullptr, k == 0, k == count - 1)) != RT_OK) return rc;
+        if ((rc = launchFrame(ctx, p, false, nullptr, k == 0, k + n >= count, n, stride)) != RT_OK) return rc;
     }
     RT_HIP(ctx, hipEventRecord(ctx->evStop, ctx->stream));
     ctx->timed = true;

@@ -699,21 +699,37 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_megakernel)(DevScene S, rt_push_
         const int mode = pc.renderMode;
         if (mode == 0 || mode == 3 || mode == 4) {
             // Pathtrace, raytrace.comp:771-817
+            // One dispatch of the shader renders one frame. L.frames > 1 (path tracing only) runs that
+            // many consecutive dispatches of this pixel back to back - frames pc.frame,
+            // pc.frame + L.frameStride, ... - with the accumulation pixel held in registers in
+            // between: the same additions in the same order as separate dispatches, the draw image
+            // written once, for the last frame.
+            const int frames = (mode == 0 && !statsOnly) ? L.frames : 1;
+            const int lastFrame = pc.frame + (frames - 1) * L.frameStride;
             float raysPerPixelRatio = 1.0f / (float)pc.raysPerPixel;
-            float accumulationMultiplier = pc.accumulateFrames == 1 ? 1.0f / (float)(pc.frame + 1) : 1.0f;
+            float accumulationMultiplier = pc.accumulateFrames == 1 ? 1.0f / (float)(lastFrame + 1) : 1.0f;
             V3 nc = mk(0.0f, 0.0f, 0.0f);
-            for (int i = 0; i < pc.raysPerPixel; ++i) {
-                uint32_t seed = seed_from_coords((uint32_t)x, (uint32_t)y, (uint32_t)pc.frame, (uint32_t)i);
-                Ray ray = get_ray(pc, x, y, seed);
-                nc = nc + ray_colour<COUNT>(S, pc, ray, seed, cnt, stack);
-                samples++;
-            }
-            if (!statsOnly) {
-                if (mode == 0) {
-                    float4 acc = accum[idx];
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int fr = 0; fr < frames; ++fr) {
+                const uint32_t frame = (uint32_t)(pc.frame + fr * L.frameStride);
+                nc = mk(0.0f, 0.0f, 0.0f);
+                for (int i = 0; i < pc.raysPerPixel; ++i) {
+                    uint32_t seed = seed_from_coords((uint32_t)x, (uint32_t)y, frame, (uint32_t)i);
+                    Ray ray = get_ray(pc, x, y, seed);
+                    nc = nc + ray_colour<COUNT>(S, pc, ray, seed, cnt, stack);
+                    samples++;
+                }
+                if (mode == 0 && !statsOnly) {
+                    // the pixel goes through memory between frames (it stays in the cache): keeping it in
+                    // registers across the whole path costs more than the round trip
+                    acc = accum[idx];
                     nc = nc * raysPerPixelRatio;
                     acc.x += nc.x; acc.y += nc.y; acc.z += nc.z;
                     accum[idx] = acc;
+                }
+            }
+            if (!statsOnly) {
+                if (mode == 0) {
                     float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(nc.x, nc.y, nc.z, 1.0f);
                     avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
                     out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);

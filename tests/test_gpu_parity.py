@@ -458,6 +458,39 @@ def test_wavefront_knobs_do_not_change_results(R, default_scene_arrays):
         r.close()
 
 
+def test_frames_per_launch_does_not_change_results(R, default_scene_arrays):
+    """rt_render_frames may run several consecutive frames of the call in one launch
+    (RT_OPT_FRAMES_PER_LAUNCH): accumulation and draw image stay what single-frame dispatches - and the
+    oracle - give, for a strided frame set with a ragged last group, both flavours, accumulation on and off."""
+    W, H = 136, 88
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays); r.resize(W, H)
+        for accumulate in (1, 0):
+            opc = scenes.make_pc(default_scene_arrays, W, H, raysPerPixel=2, accumulateFrames=accumulate)
+            frames = [2 + 3 * k for k in range(7)]
+            want = oracle_frames(default_scene_arrays, opc, frames, W, H)
+            for fast in (0, 1):
+                r.set_option(R.RT_OPT_FAST_MATH, fast)
+                r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, 1)
+                r.clear_accumulation()
+                r.render_frames(to_pc(R, opc), 2, 3, 7)
+                one = (r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW))
+                if fast == 0:
+                    assert np.array_equal(bits(one[0]), bits(want["accum"])) and np.array_equal(bits(one[1]), bits(want["out"]))
+                for group in (2, 3, 7, 8, 64):
+                    r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, group)
+                    r.clear_accumulation()
+                    r.render_frames(to_pc(R, opc), 2, 3, 7)
+                    got = (r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW))
+                    assert np.array_equal(bits(got[0]), bits(one[0])), (accumulate, fast, group)
+                    assert np.array_equal(bits(got[1]), bits(one[1])), (accumulate, fast, group)
+        with pytest.raises(R.RtError):
+            r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, 0)
+    finally:
+        r.close()
+
+
 def test_device_math_equals_host_math(R):
     """exp2 / exp / log2 / acos of include/rt_math.h: the strict kernels give the bits the host gives,
     over random inputs of every range the renderer can feed in and the special values."""
