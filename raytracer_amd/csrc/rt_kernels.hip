@@ -384,14 +384,34 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
         bool ok = (__any(parW) ? lean_box<true>(org, winv, bmn, bmx, tMin, E) : lean_box<false>(org, winv, bmn, bmx, tMin, E)) &&
                   (best.closest > E);
         if (ok) ok = !(distance_to_aabb(org, bmn, bmx) > best.closest);
-        int cur = ob->root;
-        if (!ok || !(cur > RT_REF_LIVE_MIN)) continue;
+        const int root = ob->root;   // wave-uniform
+        if (root < 0) {
+            // A parent that is one leaf (a wall: two triangles): every lane that enters tests the same
+            // triangles, so their records come through the scalar cache, once for the wave.
+            if (!(root > RT_REF_LIVE_MIN) || !__any(ok)) continue;
+            V3 lo = xform(ob->inv, org, 1.0f);
+            V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
+            const float4* tp = reinterpret_cast<const float4*>(S.tris + ~root);
+            for (;;) {
+                const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                if (ok) {
+                    if (COUNT) cnt.triTests++;
+                    if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, i, best)) {
+                        if (ANYHIT) return true;
+                    }
+                }
+                if (__float_as_int(t0.w) <= 1) break;
+                tp += 3;
+            }
+            continue;
+        }
+        int cur = root;
+        if (!ok) continue;
 
         V3 lo = xform(ob->inv, org, 1.0f);
         V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
         V3 linv = ld;
-        bool parL = false;
-        if (cur >= 0) parL = lean_inverse(ld, linv);   // a leaf parent has no boxes to test
+        const bool parL = lean_inverse(ld, linv);
         int sp = 0;
 
         for (;;) {
@@ -671,7 +691,7 @@ __device__ __forceinline__ int wave_sum(int v)
 // main(), raytrace.comp:857-875. One 64-lane block renders one 8x8 pixel tile.
 // statsOnly != 0: write no image, only add the work counters to *counters.
 template <bool COUNT>
-__global__ __launch_bounds__(64) void RT_SYM(rt_megakernel)(DevScene S, rt_push_constants pc, DevLaunch L,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT_SYM(rt_megakernel)(DevScene S, rt_push_constants pc, DevLaunch L,
                                                             float4* __restrict__ accum, float4* __restrict__ out,
                                                             DevCounters* counters, int statsOnly)
 {
