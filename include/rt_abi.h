@@ -172,9 +172,11 @@ int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16]
  * host floats on the device. A host that includes rt_math.h must get the same bits. Synchronises. */
 int rt_math_apply(rt_ctx* ctx, int which, const float* x, float* y, size_t n);
 
-/* Milliseconds the last rt_render_frame(s) call spent on the device, measured
- * with HIP events on the stream the kernels were launched on. Synchronises. */
-int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_dispatch);
+/* Milliseconds the last rt_render_frame(s) call spent on the device, measured with HIP events on
+ * the stream the kernels were launched on: the total, and the total divided by the number of frames
+ * the call rendered (one frame is one dispatch of the reference; rt_render_frames may put several
+ * frames into one kernel launch, see RT_OPT_FRAMES_PER_LAUNCH). Synchronises. */
+int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_frame);
 
 int rt_image_size(rt_ctx* ctx, int* width, int* height);
 const char* rt_last_error(rt_ctx* ctx);

@@ -54,7 +54,7 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     bool timed = false;
-    int lastDispatches = 0;
+    int lastFrames = 0;
 
     // scene in HBM
     DevScene scene{};
@@ -774,7 +774,7 @@ int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, 
     }
     RT_HIP(ctx, hipEventRecord(ctx->evStop, ctx->stream));
     ctx->timed = true;
-    ctx->lastDispatches = count;
+    ctx->lastFrames = count;
     return RT_OK;
 }
 
@@ -863,7 +863,7 @@ int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16]
     return RT_OK;
 }
 
-int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_dispatch)
+int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_frame)
 {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (!ctx->timed) return fail(ctx, RT_ERR_INVALID_ARG, "nothing has been rendered on this stream yet");
@@ -872,7 +872,7 @@ int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_dispatch)
     float ms = 0.0f;
     RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop));
     if (ms_total) *ms_total = ms;
-    if (ms_per_dispatch) *ms_per_dispatch = ctx->lastDispatches > 0 ? ms / (float)ctx->lastDispatches : 0.0f;
+    if (ms_per_frame) *ms_per_frame = ctx->lastFrames > 0 ? ms / (float)ctx->lastFrames : 0.0f;
     return RT_OK;
 }
 
