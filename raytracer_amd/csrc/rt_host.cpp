@@ -32,6 +32,8 @@ hipError_t rt_launch_megakernel_strict(const DevScene*, const rt_push_constants*
                                        DevCounters*, int, int, hipStream_t);
 hipError_t rt_launch_megakernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
                                      DevCounters*, int, int, hipStream_t);
+hipError_t rt_launch_pairkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, hipStream_t);
+hipError_t rt_launch_pairkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, hipStream_t);
 hipError_t rt_launch_schedkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
                                         DevCounters*, int, int, unsigned long long*, int, hipStream_t, unsigned long long*);
 hipError_t rt_launch_schedkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
@@ -465,6 +467,9 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
         auto fn = ctx->optFast ? rt_launch_schedkernel_fast : rt_launch_schedkernel_strict;
         e = fn(&ctx->scene, &pc, &L, ctx->accum, ctx->draw, statsOnly ? ctx->dCounters : nullptr, countBuild ? 1 : 0,
                statsOnly ? 1 : 0, ctx->dQueue, blocks, ctx->stream, diag);
+    } else if (ctx->optPipeline == 3 && pc.renderMode == 0 && !statsOnly && pc.raysPerPixel >= 1 && (long long)frames * pc.raysPerPixel >= 2) {
+        auto fn = ctx->optFast ? rt_launch_pairkernel_fast : rt_launch_pairkernel_strict;
+        e = fn(&ctx->scene, &pc, &L, ctx->accum, ctx->draw, ctx->stream);
     } else {
         // the depth / box views and the degenerate raysPerPixel <= 0 case stay on the lock-step kernel
         auto fn = ctx->optFast ? rt_launch_megakernel_fast : rt_launch_megakernel_strict;
@@ -545,7 +550,7 @@ int rt_set_option(rt_ctx* ctx, int option, int value)
     switch (option) {
     case RT_OPT_FAST_MATH: ctx->optFast = value ? 1 : 0; return RT_OK;
     case RT_OPT_PIPELINE:
-        if (value < 0 || value > 2) return fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step), 1 (wave-scheduled) or 2 (wavefront)");
+        if (value < 0 || value > 3) return fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step), 1 (wave-scheduled), 2 (wavefront) or 3 (lock-step, two samples per lane)");
         ctx->optPipeline = value;
         return RT_OK;
     case RT_OPT_WAVES_PER_CU:
@@ -765,7 +770,7 @@ int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, 
     rt_push_constants p = *pc;
     // the lock-step kernel can run several consecutive frames of a pixel in one launch (same
     // arithmetic in the same order, one read and one write of the accumulation pixel)
-    const bool fuse = ctx->optPipeline == 0 && pc->renderMode == 0 && pc->raysPerPixel >= 1 && ctx->framesPerLaunch > 1;
+    const bool fuse = (ctx->optPipeline == 0 || ctx->optPipeline == 3) && pc->renderMode == 0 && pc->raysPerPixel >= 1 && ctx->framesPerLaunch > 1;
     const int group = fuse ? ctx->framesPerLaunch : 1;
     for (int k = 0; k < count; k += group) {
         const int n = std::min(group, count - k);

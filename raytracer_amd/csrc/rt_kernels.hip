@@ -678,6 +678,179 @@ __device__ __forceinline__ V3 ray_colour(const DevScene& S, const rt_push_consta
     return result;
 }
 
+// ---- two samples per lane ------------------------------------------------------------------
+//
+// A wave leaves a BVH walk when its slowest lane does, and walks are short on average (11 steps)
+// with a long tail (a few hundred), so a wave of 64 rays spends most of a walk waiting for one or two
+// lanes. Giving every lane TWO independent samples of its pixel (consecutive entries of the pixel's
+// sample sequence: frames and samples per pixel) and letting it walk the second ray as soon as its
+// first is done makes the wave wait for the largest SUM of two walks instead of twice for the largest
+// walk; sums of two have a much lighter tail. The parents are still visited by the whole wave in
+// step (their records stay scalar); inside a BVH parent a lane walks ray A, then ray B. Each ray sees
+// the objects, nodes and triangles in the reference's order, and the two samples are added to the
+// pixel in sequence order, so the image is the one the one-sample kernel renders.
+
+struct PathState {
+    V3 o, d;              // next regular ray (d as the shader keeps it)
+    V3 throughput, result;
+    V3 sun;               // sun term of the last hit, added when its shadow ray comes back unblocked
+    V3 so;                // origin of that shadow ray
+    uint32_t seed;
+    bool alive;           // wants a regular GetHit
+    bool shadow;          // wants a shadow GetHit
+};
+
+__device__ __forceinline__ void best_reset(Best& b, float tMax)
+{
+    b.closest = tMax; b.object = -1; b.tri = 0; b.u = 0.0f; b.v = 0.0f; b.tLocal = 0.0f;
+}
+
+// GetHit for two rays per lane (see above). onA / onB: the lane has such a ray. ANYHIT: shadow rays,
+// leaf parents first, a ray stops at its first accepted hit.
+template <bool ANYHIT>
+__device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V3 oA, V3 dA, bool onA, Best& bA, V3 oB, V3 dB, bool onB,
+                                           Best& bB, float tMin, float tMax, uint2* stack)
+{
+    best_reset(bA, tMax);
+    best_reset(bB, tMax);
+    V3 winvA, winvB;
+    const bool parWA = lean_inverse(dA, winvA) && onA, parWB = lean_inverse(dB, winvB) && onB;
+    const bool permute = ANYHIT && parentCount == S.objectCount;
+    for (int pos = 0; pos < parentCount; ++pos) {
+        const int i = permute ? S.anyOrder[pos] : pos;
+        const DevObject* ob = S.objects + i;   // wave-uniform address
+        const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+        const bool liveA = onA && !(ANYHIT && bA.object >= 0), liveB = onB && !(ANYHIT && bB.object >= 0);
+        if (ANYHIT && !__any(liveA || liveB)) break;
+        float E;
+        bool okA = liveA && (__any(parWA) ? lean_box<true>(oA, winvA, bmn, bmx, tMin, E) : lean_box<false>(oA, winvA, bmn, bmx, tMin, E)) &&
+                   (bA.closest > E);
+        if (okA) okA = !(distance_to_aabb(oA, bmn, bmx) > bA.closest);
+        bool okB = liveB && (__any(parWB) ? lean_box<true>(oB, winvB, bmn, bmx, tMin, E) : lean_box<false>(oB, winvB, bmn, bmx, tMin, E)) &&
+                   (bB.closest > E);
+        if (okB) okB = !(distance_to_aabb(oB, bmn, bmx) > bB.closest);
+        const int root = ob->root;   // wave-uniform
+        if (!(root > RT_REF_LIVE_MIN) || !__any(okA || okB)) continue;
+        if (root < 0) {
+            // one leaf (a wall): records through the scalar cache, both rays test them
+            const V3 loA = xform(ob->inv, oA, 1.0f), ldA = normalize3(xform(ob->inv, dA, 0.0f));
+            const V3 loB = xform(ob->inv, oB, 1.0f), ldB = normalize3(xform(ob->inv, dB, 0.0f));
+            const float4* tp = reinterpret_cast<const float4*>(S.tris + ~root);
+            for (;;) {
+                const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                if (okA && triangle_hit(t0, t1, t2, loA, ldA, ob->fwd, oA, dA, tMin, i, bA) && ANYHIT) okA = false;
+                if (okB && triangle_hit(t0, t1, t2, loB, ldB, ob->fwd, oB, dB, tMin, i, bB) && ANYHIT) okB = false;
+                if (__float_as_int(t0.w) <= 1) break;
+                tp += 3;
+            }
+            continue;
+        }
+        if (!(okA || okB)) continue;
+
+        // the ray being walked: A first, then B
+        bool second = !okA;
+        V3 org = second ? oB : oA, dirN = second ? dB : dA;
+        Best bw = second ? bB : bA;
+        V3 lo = xform(ob->inv, org, 1.0f);
+        V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
+        V3 linv = ld;
+        bool parL = lean_inverse(ld, linv);
+        int cur = root, sp = 0;
+        for (;;) {
+            while ((unsigned)cur < (unsigned)RT_NONE) {
+                NodeVisit nv;
+                visit_node(S, cur, lo, linv, __any(parL), tMin, nv);
+                const int2 refs = nv.refs;
+                const bool goF = refs.x > RT_REF_LIVE_MIN && nv.okF && (bw.closest > nv.EF);
+                const bool canS = refs.y > RT_REF_LIVE_MIN && nv.okS;
+                if (goF) {
+                    if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(nv.ES)); ++sp; }
+                    cur = refs.x;
+                } else if (canS && (bw.closest > nv.ES)) {
+                    cur = refs.y;
+                } else {
+                    cur = RT_NONE;
+                    while (sp > 0) {
+                        --sp;
+                        uint2 e = stack[sp * 64];
+                        if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                    }
+                }
+            }
+            if (cur != RT_NONE) {
+                int k = ~cur;
+                bool stop = false;
+                for (;;) {
+                    const float4* tp = reinterpret_cast<const float4*>(S.tris + k);
+                    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    const int remaining = __float_as_int(t0.w);
+                    if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, i, bw) && ANYHIT) { stop = true; break; }
+                    if (remaining <= 1) break;
+                    ++k;
+                }
+                cur = RT_NONE;
+                if (stop) sp = 0;
+                while (sp > 0) {
+                    --sp;
+                    uint2 e = stack[sp * 64];
+                    if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                }
+            }
+            if (cur == RT_NONE) {
+                // this ray has nothing left in this object
+                if (second) { bB = bw; break; }
+                bA = bw;
+                if (!okB) break;
+                second = true;
+                org = oB; dirN = dB; bw = bB;
+                lo = xform(ob->inv, org, 1.0f);
+                ld = normalize3(xform(ob->inv, dirN, 0.0f));
+                linv = ld;
+                parL = lean_inverse(ld, linv);
+                cur = root; sp = 0;
+            }
+        }
+    }
+}
+
+// The part of RayColour's loop body between two GetHit calls (raytrace.comp:701-766) for one path:
+// takes the regular hit, adds sky / emission, ends the path or prepares the shadow ray (sun term kept
+// aside until the shadow ray's answer is in) and the next regular ray.
+__device__ __forceinline__ void pair_shade(const DevScene& S, const rt_push_constants& pc, PathState& p, V3 dirN, const Best& best)
+{
+    p.shadow = false;
+    if (!p.alive) return;
+    HitRec rec;
+    finish_hit(S, p.o, dirN, best, rec);
+    if (!rec.hit) {
+        p.result = p.result + p.throughput * environment_colour(pc, p.d);
+        p.alive = false;
+        return;
+    }
+    if (!rec.frontFace) { p.alive = false; return; }
+    DevMaterial m = load_material(S, rec.matIndex);
+    V3 emitted = ld3(m.colour) * m.emission;
+    p.result = p.result + p.throughput * emitted;
+    if (m.emission > 0.0f) { p.alive = false; return; }
+    V3 negSun = -ld3(pc.sunDirection);
+    float nDotL = gmax(dot3(rec.normal, negSun), 0.0f);
+    if (nDotL > 0.0f) {
+        p.shadow = true;
+        p.so = rec.point + rec.normal * 0.01f;
+        V3 sun = ld3(pc.sunColour) * pc.sunIntensity;
+        const float INV_PI = 0.31830988618f;
+        V3 direct = sun * (nDotL * INV_PI);
+        if (m.refractionIndex == 0.0f) p.sun = (p.throughput * ld3(m.colour)) * direct;
+        else p.sun = (p.throughput * reflectance(nDotL, m.refractionIndex)) * direct;
+    }
+    V3 attenuation;
+    Ray scattered;
+    material_scatter(m, p.d, rec, p.seed, attenuation, scattered);
+    p.throughput = p.throughput * attenuation;
+    p.o = scattered.o;
+    p.d = scattered.d;
+}
+
 __device__ __forceinline__ float linear_to_gamma(float c) { return c > 0.0f ? sqrtf(c) : 0.0f; }
 
 __device__ __forceinline__ int wave_sum(int v)
@@ -801,6 +974,89 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT
             atomicAdd(&counters->samples, (unsigned long long)s);
         }
     }
+}
+
+// Pathtrace (raytrace.comp:771-817) with two samples per lane: the samples of a pixel - frames
+// pc.frame, pc.frame + L.frameStride, ... (L.frames of them), pc.raysPerPixel samples each - are taken
+// two at a time, traced together by trace_pair() and added to the pixel in sequence order.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT_SYM(rt_pairkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
+                                                            float4* __restrict__ accum, float4* __restrict__ out)
+{
+    extern __shared__ uint2 stackMem[];
+    const int lane = threadIdx.x;
+    uint2* stack = stackMem + lane;
+
+    const int wavesX = L.tileSize >> 3;
+    const int wavesPerTile = wavesX * wavesX;
+    const int ownedTile = blockIdx.x / wavesPerTile;
+    const int sub = blockIdx.x - ownedTile * wavesPerTile;
+    const int tile = L.tileRank + ownedTile * L.tileWorld;
+    const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
+    const int sy = sub / wavesX, sx = sub - sy * wavesX;
+    const int x = tx * L.tileSize + sx * 8 + (lane & 7);
+    const int y = ty * L.tileSize + sy * 8 + (lane >> 3);
+    if (!(x < L.width && y < L.height)) return;
+    const size_t idx = (size_t)y * (size_t)L.width + (size_t)x;
+
+    const int rpp = pc.raysPerPixel;
+    const int total = L.frames * rpp;                 // samples of this pixel in this launch
+    const int bounces = pc.maxBounces + 1;
+    const float raysPerPixelRatio = 1.0f / (float)rpp;
+    const V3 sunDirN = normalize3(-ld3(pc.sunDirection));
+    V3 nc = mk(0.0f, 0.0f, 0.0f);
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+    for (int n = 0; n < total; n += 2) {
+        PathState P[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = n + q;
+            PathState& p = P[q];
+            p.alive = m < total;
+            p.shadow = false;
+            p.throughput = mk(1.0f, 1.0f, 1.0f);
+            p.result = mk(0.0f, 0.0f, 0.0f);
+            p.sun = mk(0.0f, 0.0f, 0.0f);
+            p.so = mk(0.0f, 0.0f, 0.0f);
+            const int fr = m / rpp, i = m - fr * rpp;
+            p.seed = seed_from_coords((uint32_t)x, (uint32_t)y, (uint32_t)(pc.frame + fr * L.frameStride), (uint32_t)i);
+            Ray ray = get_ray(pc, x, y, p.seed);
+            p.o = ray.o; p.d = ray.d;
+        }
+        for (int bounce = 0; bounce < bounces; ++bounce) {
+            if (!(P[0].alive || P[1].alive)) break;
+            const V3 dirA = normalize3(P[0].d), dirB = normalize3(P[1].d);
+            Best bA, bB;
+            trace_pair<false>(S, pc.parentBVHCount, P[0].o, dirA, P[0].alive, bA, P[1].o, dirB, P[1].alive, bB, 0.001f, 1e20f, stack);
+            pair_shade(S, pc, P[0], dirA, bA);
+            pair_shade(S, pc, P[1], dirB, bB);
+            if (P[0].shadow || P[1].shadow) {
+                trace_pair<true>(S, pc.parentBVHCount, P[0].so, sunDirN, P[0].shadow, bA, P[1].so, sunDirN, P[1].shadow, bB, 0.001f, 1e20f, stack);
+                if (P[0].shadow && bA.object < 0) P[0].result = P[0].result + P[0].sun;
+                if (P[1].shadow && bB.object < 0) P[1].result = P[1].result + P[1].sun;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = n + q;
+            if (m >= total) break;
+            nc = nc + P[q].result;
+            const int fr = m / rpp, i = m - fr * rpp;
+            if (i == rpp - 1) {
+                // end of a frame: the pixel goes through memory as in the one-sample kernel
+                acc = accum[idx];
+                nc = nc * raysPerPixelRatio;
+                acc.x += nc.x; acc.y += nc.y; acc.z += nc.z;
+                accum[idx] = acc;
+                if (m + 1 < total) nc = mk(0.0f, 0.0f, 0.0f);
+            }
+        }
+    }
+    const int lastFrame = pc.frame + (L.frames - 1) * L.frameStride;
+    const float accumulationMultiplier = pc.accumulateFrames == 1 ? 1.0f / (float)(lastFrame + 1) : 1.0f;
+    float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(nc.x, nc.y, nc.z, 1.0f);
+    avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
+    out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1901,6 +2157,18 @@ extern "C" hipError_t RT_SYM(rt_launch_megakernel)(const DevScene* S, const rt_p
     else
         hipLaunchKernelGGL(RT_SYM(rt_megakernel)<false>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out,
                            counters, statsOnly);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_push_constants* pc, const DevLaunch* L,
+                                                   void* accum, void* out, hipStream_t stream)
+{
+    const int wavesX = L->tileSize / 8;
+    const long long blocks = (long long)L->ownedTiles * wavesX * wavesX;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
+    hipLaunchKernelGGL(RT_SYM(rt_pairkernel), dim3((unsigned)blocks), dim3(64), lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
     return hipGetLastError();
 }
 

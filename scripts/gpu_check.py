@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import raytracer_amd as R
 import oracle_lib as O
 
-pipes = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
+pipes = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3]
 W, H = 320, 180
 s = R.Scene(); s.init_default(); sb = s.buffers(); arrays = sb.to_arrays()
 r = R.Renderer(0)
