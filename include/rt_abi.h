@@ -56,7 +56,13 @@ enum {
      * results. 2 = wavefront: a ray that enters the box of a BVH parent is suspended (state in
      * HBM) and a second kernel, in which every lane takes the next ray as soon as its walk is
      * done, finishes its GetHit; further rounds of the path kernel pick the paths up again.
-     * Needs 176 bytes of device memory per pixel. Same arithmetic, same results. */
+     * Needs 176 bytes of device memory per pixel. Same arithmetic, same results. 3 = lock-step
+     * with two samples per lane: when an rt_render_frames launch holds at least two samples of a
+     * pixel (frames per launch x raysPerPixel), every lane traces two of them together and walks
+     * its second ray while other lanes of the wave are still on their first, so the wave waits for
+     * the largest sum of two walks instead of twice for the largest walk. Each ray sees objects,
+     * nodes and triangles in the reference's order and the samples are added in sequence order:
+     * same results. Other launches (one sample, debug views, counters) use kernel 0. */
     RT_OPT_PIPELINE    = 2,
     /* Tile partition for multi-GPU tile split: this context renders only the
      * tiles t with t % RT_OPT_TILE_WORLD == RT_OPT_TILE_RANK (tiles are

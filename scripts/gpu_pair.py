@@ -12,22 +12,22 @@ for (W, H, rpp, first, stride, count, acc) in [(320, 180, 1, 0, 1, 8, 1), (200, 
     pc = R.default_push_constants(); R.camera_to_push_constants(cam, W, H, pc); pc.parentBVHCount = 8
     pc.raysPerPixel = rpp; pc.accumulateFrames = acc
     imgs = []
-    for pipe in (0, 3):
+    for pipe, q in ((0, 2), (3, 2)):
         r.set_option(R.RT_OPT_PIPELINE, pipe)
         r.clear_accumulation()
         r.render_frames(pc, first, stride, count); r.sync()
         imgs.append((r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW)))
     print("%dx%d rpp=%d frames %d+%d*k x%d acc=%d: accum equal %.4f%% draw equal %.4f%%" % (W, H, rpp, first, stride, count, acc,
-          100.0 * np.mean(np.all(imgs[0][0].view(np.uint32) == imgs[1][0].view(np.uint32), axis=2)),
-          100.0 * np.mean(np.all(imgs[0][1].view(np.uint32) == imgs[1][1].view(np.uint32), axis=2))), flush=True)
+          min(100.0 * np.mean(np.all(imgs[0][0].view(np.uint32) == im[0].view(np.uint32), axis=2)) for im in imgs[1:]),
+          min(100.0 * np.mean(np.all(imgs[0][1].view(np.uint32) == im[1].view(np.uint32), axis=2)) for im in imgs[1:])), flush=True)
 W, H = 2560, 1369
 r.resize(W, H)
 pc = R.default_push_constants(); R.camera_to_push_constants(cam, W, H, pc); pc.parentBVHCount = 8
 st = r.frame_stats(pc)
-for pipe in (0, 3, 0, 3):
+for pipe, q in ((0, 2), (3, 2), (0, 2), (3, 2)):
     r.set_option(R.RT_OPT_PIPELINE, pipe)
     r.render_frames(pc, 0, 1, 16); r.sync()
     r.clear_accumulation()
     r.render_frames(pc, 0, 1, 32); r.sync()
     ms = r.last_render_ms()[1]
-    print("pipeline=%d 2560x1369: %.3f ms/frame -> %.1f Mrays/s" % (pipe, ms, st.rays / (ms * 1e-3) / 1e6), flush=True)
+    print("pipeline=%d q=%d 2560x1369: %.3f ms/frame -> %.1f Mrays/s" % (pipe, q, ms, st.rays / (ms * 1e-3) / 1e6), flush=True)

@@ -29,7 +29,7 @@ def R():
     return raytracer_amd
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2], ids=["lockstep", "scheduled", "wavefront"])
+@pytest.fixture(scope="module", params=[0, 1, 2, 3], ids=["lockstep", "scheduled", "wavefront", "two-samples"])
 def rdr(R, default_scene_arrays, request):
     """One renderer per kernel choice: every test that takes `rdr` runs on all pipelines."""
     r = R.Renderer(0)
@@ -231,6 +231,47 @@ def test_mixed_material_scene(R, pipeline):
         r.render_frame(to_pc(R, opc2))
         want = O.render(arrays, O.pc_bytes(opc2), W, H)["out"]
         assert np.array_equal(bits(r.read_image(R.RT_IMAGE_DRAW)), bits(want))
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("fused", [8, 3], ids=["launch8", "launch3"])
+def test_two_samples_per_lane_bit_exact(R, default_scene_arrays, fused):
+    """Pipeline 3 traces two samples of a pixel per lane (a lane walks its second ray while other lanes
+    are still on their first). Against the oracle: default scene with 3 samples per pixel over a strided,
+    ragged frame set (pairs straddle frame boundaries; the last pair is half empty), accumulation on and
+    off, and the mixed-material scene (glass, sky, scaled objects, a 287-triangle leaf, deeper bounces)."""
+    r = R.Renderer(0)
+    try:
+        r.set_option(R.RT_OPT_PIPELINE, 3)
+        r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, fused)
+        W, H = 136, 88
+        r.upload_scene(default_scene_arrays); r.resize(W, H)
+        for accumulate in (1, 0):
+            opc = scenes.make_pc(default_scene_arrays, W, H, raysPerPixel=3, accumulateFrames=accumulate)
+            frames = [1 + 2 * k for k in range(5)]
+            want = oracle_frames(default_scene_arrays, opc, frames, W, H)
+            r.clear_accumulation()
+            r.render_frames(to_pc(R, opc), 1, 2, 5)
+            assert np.array_equal(bits(r.read_image(R.RT_IMAGE_ACCUM)), bits(want["accum"])), accumulate
+            assert np.array_equal(bits(r.read_image(R.RT_IMAGE_DRAW)), bits(want["out"])), accumulate
+        materials, objects = scenes.mixed_recipe()
+        arrays = scenes.build_oracle(materials, objects).bindings()
+        r.upload_scene(arrays)
+        W, H = 192, 108
+        r.resize(W, H)
+        opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 2.5, 8.0), look=(0.0, -0.15, -1.0), fov=60.0, maxBounces=5, raysPerPixel=2)
+        want = oracle_frames(arrays, opc, [0, 1, 2], W, H)
+        r.clear_accumulation()
+        r.render_frames(to_pc(R, opc), 0, 1, 3)
+        assert np.array_equal(bits(r.read_image(R.RT_IMAGE_ACCUM)), bits(want["accum"]))
+        assert np.array_equal(bits(r.read_image(R.RT_IMAGE_DRAW)), bits(want["out"]))
+        # the fast flavour stays within its tolerance of the strict one
+        r.set_option(R.RT_OPT_FAST_MATH, 1)
+        r.clear_accumulation()
+        r.render_frames(to_pc(R, opc), 0, 1, 3)
+        # (a contracted multiply-add can flip a refraction or a scatter decision: a few pixels take another path)
+        assert within(r.read_image(R.RT_IMAGE_ACCUM)[..., :3], want["accum"][..., :3], 1e-3, 1e-3) > 0.98
     finally:
         r.close()
 
@@ -472,19 +513,22 @@ def test_frames_per_launch_does_not_change_results(R, default_scene_arrays):
             want = oracle_frames(default_scene_arrays, opc, frames, W, H)
             for fast in (0, 1):
                 r.set_option(R.RT_OPT_FAST_MATH, fast)
-                r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, 1)
-                r.clear_accumulation()
-                r.render_frames(to_pc(R, opc), 2, 3, 7)
-                one = (r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW))
-                if fast == 0:
-                    assert np.array_equal(bits(one[0]), bits(want["accum"])) and np.array_equal(bits(one[1]), bits(want["out"]))
-                for group in (2, 3, 7, 8, 64):
-                    r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, group)
+                for pipeline in (0, 3):   # 3: two samples per lane, pairs formed inside a launch
+                    r.set_option(R.RT_OPT_PIPELINE, pipeline)
+                    r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, 1)
                     r.clear_accumulation()
                     r.render_frames(to_pc(R, opc), 2, 3, 7)
-                    got = (r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW))
-                    assert np.array_equal(bits(got[0]), bits(one[0])), (accumulate, fast, group)
-                    assert np.array_equal(bits(got[1]), bits(one[1])), (accumulate, fast, group)
+                    one = (r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW))
+                    if fast == 0:   # (the fast flavour is only the same from launch shape to launch shape of one kernel)
+                        assert np.array_equal(bits(one[0]), bits(want["accum"])) and np.array_equal(bits(one[1]), bits(want["out"]))
+                    for group in (2, 3, 7, 8, 64):
+                        r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, group)
+                        r.clear_accumulation()
+                        r.render_frames(to_pc(R, opc), 2, 3, 7)
+                        got = (r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW))
+                        assert np.array_equal(bits(got[0]), bits(one[0])), (accumulate, fast, pipeline, group)
+                        assert np.array_equal(bits(got[1]), bits(one[1])), (accumulate, fast, pipeline, group)
+                r.set_option(R.RT_OPT_PIPELINE, 0)
         with pytest.raises(R.RtError):
             r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, 0)
     finally:
