@@ -148,7 +148,8 @@ def main():
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        # one launch of the megakernel renders `group` consecutive frames (RT_OPT_FRAMES_PER_LAUNCH)
+        # one launch of the kernel (default: rt_pairkernel, two samples per lane) renders `group` consecutive frames
+        # (RT_OPT_FRAMES_PER_LAUNCH)
         group = r.get_option(R.RT_OPT_FRAMES_PER_LAUNCH)
         launches = (spp + group - 1) // group
         launch_ms = float(np.mean(kernel_ms)) / launches      # average duration of one launch of the megakernel
@@ -175,7 +176,7 @@ def main():
             "rays_per_step": total_rays,
             "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rt_megakernel", "launch_ms": launch_ms, "frames_per_launch": group,
+                         "kernel": {0: "rt_megakernel", 3: "rt_pairkernel"}.get(r.get_option(R.RT_OPT_PIPELINE), "pipeline %d" % r.get_option(R.RT_OPT_PIPELINE)), "launch_ms": launch_ms, "frames_per_launch": group,
                          "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "valu": {"achieved_tflops": flops_per_launch / (launch_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
                                   "frac": flops_per_launch / (launch_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},

@@ -95,7 +95,7 @@ struct rt_ctx {
     int wfRounds = 5, wfRefill = 16, wfWalkWaves = 12, wfParts = 1;
     int framesPerLaunch = 8;
 
-    int optFast = 0, optPipeline = 0, tileRank = 0, tileWorld = 1, tileSize = 64;
+    int optFast = 0, optPipeline = 3, tileRank = 0, tileWorld = 1, tileSize = 64;
     std::string error;
 };
 
