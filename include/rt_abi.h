@@ -169,6 +169,20 @@ int rt_resolve(rt_ctx* ctx, int total_frames);
  * the number of GetHit calls). Synchronises. */
 int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out);
 
+/* rt_frame_stats_compute for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc. It has no counterpart in the reference. The call itself
+ * allocates nothing, on the device or through the HIP runtime (only a failure builds its message on
+ * the host heap): every wave of the counting kernel stores its counters into its own slot of a
+ * file-scope device array that is part of the library's code object (4 MiB per GPU, held until the
+ * process ends), and a second kernel adds the slots up into *out_dev. Differences from
+ * rt_frame_stats_compute: always the lock-step counting kernel, whatever RT_OPT_PIPELINE says (same
+ * counters); out_dev must be memory the GPU can write (device memory or pinned host memory); the call
+ * only enqueues on the context's stream and does not synchronise (read *out_dev after rt_sync);
+ * a dispatch of more than 131 072 waves of 8x8 pixels (8 388 608 pixels, e.g. above 3840x2160) is
+ * refused with RT_ERR_UNSUPPORTED. All contexts on one GPU share that GPU's array: calls that overlap
+ * on one GPU (different contexts or streams) race; calls on one stream are ordered. */
+int rt_frame_stats_noalloc(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out_dev);
+
 /* Diagnostics of the wave-scheduled kernel (no counterpart in the reference): renders the
  * dispatch without writing images and returns, for k = 0 object/shade iterations and k = 1
  * BVH-round steps: out[2k] = wave-level executions, out[2k+1] = lanes that took part

@@ -132,6 +132,7 @@ def load_library():
         "rt_render_frame": (ci, [vp, P(PushConstants)]), "rt_render_frames": (ci, [vp, P(PushConstants), ci, ci, ci]),
         "rt_sync": (ci, [vp]), "rt_read_image": (ci, [vp, ci, vp, C.c_size_t]), "rt_write_accum": (ci, [vp, vp, C.c_size_t]),
         "rt_resolve": (ci, [vp, ci]), "rt_frame_stats_compute": (ci, [vp, P(PushConstants), P(FrameStats)]),
+        "rt_frame_stats_noalloc": (ci, [vp, P(PushConstants), vp]),
         "rt_schedule_stats": (ci, [vp, P(PushConstants), P(C.c_uint64)]),
         "rt_last_render_ms": (ci, [vp, P(cf), P(cf)]), "rt_image_size": (ci, [vp, P(ci), P(ci)]),
         "rt_last_error": (C.c_char_p, [vp]), "rt_version": (C.c_char_p, []),
@@ -171,7 +172,7 @@ EXPORTED_SYMBOLS = [
     "rt_scene_load_model", "rt_scene_add_object", "rt_scene_set_object", "rt_scene_set_material", "rt_scene_buffer_data",
     "rt_scene_get_buffers", "rt_scene_init_default", "rt_scene_model_info", "rt_rgba32f_to_rgba8", "rt_write_png_rgba8",
     "rt_save_png", "rt_produce_render", "rt_math_apply", "rt_scene_object_count", "rt_scene_material_count",
-    "rt_scene_get_object", "rt_scene_get_material"]
+    "rt_scene_get_object", "rt_scene_get_material", "rt_frame_stats_noalloc"]
 
 
 def _f3(v):
@@ -377,6 +378,11 @@ class Renderer:
         st = FrameStats()
         self._check(self.lib.rt_frame_stats_compute(self.h, C.byref(pc), C.byref(st)))
         return st
+
+    def frame_stats_noalloc(self, pc, out_ptr):
+        """rt_frame_stats_noalloc: enqueue only; out_ptr is the address of 32 bytes the GPU can write
+        (four uint64: rays, bvhNodeTests, triangleTests, samples), valid after sync()."""
+        self._check(self.lib.rt_frame_stats_noalloc(self.h, C.byref(pc), out_ptr))
 
     def schedule_stats(self, pc):
         out = (C.c_uint64 * 16)()

@@ -48,6 +48,11 @@ hipError_t rt_launch_math_strict(int, const float*, float*, size_t, hipStream_t)
 hipError_t rt_launch_math_fast(int, const float*, float*, size_t, hipStream_t);
 hipError_t rt_launch_resolve_strict(const void*, void*, size_t, float, hipStream_t);
 hipError_t rt_launch_resolve_fast(const void*, void*, size_t, float, hipStream_t);
+// rt_noalloc.hip: per-wave counter slots in a file-scope device array
+hipError_t rt_noalloc_setup(int device);
+void* rt_noalloc_scratch(int device);
+long long rt_noalloc_max_waves(void);
+hipError_t rt_noalloc_sum(const void* partials, int n, void* out, hipStream_t stream);
 }
 
 struct rt_ctx {
@@ -503,7 +508,8 @@ int rt_create(int device_id, rt_ctx** out_ctx)
         (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
         (e = hipMalloc((void**)&c->dCounters, sizeof(DevCounters))) != hipSuccess ||
         (e = hipMalloc((void**)&c->dQueue, 256)) != hipSuccess ||
-        (e = hipDeviceGetAttribute(&c->computeUnits, hipDeviceAttributeMultiprocessorCount, device_id)) != hipSuccess) {
+        (e = hipDeviceGetAttribute(&c->computeUnits, hipDeviceAttributeMultiprocessorCount, device_id)) != hipSuccess ||
+        (e = rt_noalloc_setup(device_id)) != hipSuccess) {
         int rc = failHip(nullptr, e, "rt_create");
         rt_destroy(c);
         return rc;
@@ -849,6 +855,37 @@ int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_st
     out->bvhNodeTests = h.nodeTests;
     out->triangleTests = h.triTests;
     out->samples = h.samples;
+    return RT_OK;
+}
+
+int rt_frame_stats_noalloc(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out_dev)
+{
+    int rc = checkRenderable(ctx, pc);
+    if (rc != RT_OK) return rc;
+    if (!out_dev) return fail(ctx, RT_ERR_INVALID_ARG, "null stats pointer");
+    static_assert(sizeof(rt_frame_stats) == sizeof(DevCounters), "rt_frame_stats and DevCounters share one layout");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        // the kernels store the result themselves: it has to be memory the GPU can write
+        hipPointerAttribute_t at{};
+        hipError_t e = hipPointerGetAttributes(&at, out_dev);
+        if (e != hipSuccess) (void)hipGetLastError();
+        if (e != hipSuccess || !(at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged))
+            return fail(ctx, RT_ERR_INVALID_ARG, "rt_frame_stats_noalloc: out_dev must be device memory or pinned host memory");
+    }
+    const DevLaunch L = makeLaunch(ctx);
+    const long long waves = (long long)L.ownedTiles * (L.tileSize / 8) * (L.tileSize / 8);
+    if (waves > rt_noalloc_max_waves())
+        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_frame_stats_noalloc: this dispatch needs " + std::to_string(waves) +
+                                                 " per-wave counter slots, the static scratch array holds " +
+                                                 std::to_string(rt_noalloc_max_waves()) + " (use rt_frame_stats_compute)");
+    void* slots = rt_noalloc_scratch(ctx->device);
+    if (!slots) return fail(ctx, RT_ERR_HIP, "rt_frame_stats_noalloc: the scratch array was not set up on this device");
+    // always the lock-step counting kernel: the other pipelines' counting passes use allocated queues
+    auto fn = ctx->optFast ? rt_launch_megakernel_fast : rt_launch_megakernel_strict;
+    hipError_t e = fn(&ctx->scene, pc, &L, ctx->accum, ctx->draw, static_cast<DevCounters*>(slots), 1, 2, ctx->stream);
+    if (e == hipSuccess) e = rt_noalloc_sum(slots, (int)waves, out_dev, ctx->stream);
+    if (e != hipSuccess) return failHip(ctx, e, "rt_frame_stats_noalloc launch");
     return RT_OK;
 }
 

@@ -862,7 +862,8 @@ __device__ __forceinline__ int wave_sum(int v)
 } // namespace
 
 // main(), raytrace.comp:857-875. One 64-lane block renders one 8x8 pixel tile.
-// statsOnly != 0: write no image, only add the work counters to *counters.
+// statsOnly != 0: write no image, only report the work counters: 1 = added to *counters, 2 = every
+// wave stores its own record at counters[blockIdx.x] (the caller sums them).
 template <bool COUNT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT_SYM(rt_megakernel)(DevScene S, rt_push_constants pc, DevLaunch L,
                                                             float4* __restrict__ accum, float4* __restrict__ out,
@@ -967,7 +968,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT
 
     if (COUNT && counters != nullptr) {
         int r = wave_sum(cnt.rays), n = wave_sum(cnt.nodeTests), t = wave_sum(cnt.triTests), s = wave_sum(samples);
-        if (lane == 0) {
+        if (lane == 0 && statsOnly == 2) {
+            // every wave stores its own record (no record is shared, nothing has to start at zero)
+            DevCounters c;
+            c.rays = (unsigned long long)r; c.nodeTests = (unsigned long long)n; c.triTests = (unsigned long long)t;
+            c.samples = (unsigned long long)s;
+            counters[blockIdx.x] = c;
+        } else if (lane == 0) {
             atomicAdd(&counters->rays, (unsigned long long)r);
             atomicAdd(&counters->nodeTests, (unsigned long long)n);
             atomicAdd(&counters->triTests, (unsigned long long)t);
