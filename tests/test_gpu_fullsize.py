@@ -1,0 +1,201 @@
+"""GPU parity at the sizes the benchmark configurations name, through the C ABI.
+
+The oracle renders a 2560x1369 frame of the default scene in about a second per frame on 16 threads, but
+a million-triangle frame or 64 frames at 4K are out of a test's reach, so every case here combines
+  * whole-image identities between entry points / kernels that must hold bit for bit (one multi-frame
+    launch of the default kernel == single-frame dispatches of the lock-step kernel; every pipeline gives
+    the same image; the work counters of every counting build agree), with
+  * oracle renders of small windows of the full-size frame (a pixel does not depend on its neighbours),
+    bit for bit, placed on the parts of the image that exercise different code: the dragon's BVH, the
+    edges between walls, the emitter, the ragged last rows of a height that is not a multiple of 8.
+Bar: strict flavour, accumulation and draw image BIT-EXACT (binary32 compared as uint32)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def to_pc(R, opc):
+    return R.PushConstants.from_buffer_copy(O.pc_bytes(opc).tobytes())
+
+
+def oracle_window(arrays, opc, frames, W, H, window):
+    """Accumulate `frames` in the oracle over one window; returns (accum, out) crops."""
+    x0, y0, x1, y1 = window
+    acc = np.zeros((H, W, 4), np.float32)
+    res = None
+    for f in frames:
+        opc["frame"] = f
+        res = O.render(arrays, O.pc_bytes(opc), W, H, accum=acc, window=window)
+        acc = res["accum"]
+    return res["accum"][y0:y1, x0:x1], res["out"][y0:y1, x0:x1]
+
+
+def check_windows(arrays, opc, frames, W, H, windows, acc, out, what):
+    for win in windows:
+        x0, y0, x1, y1 = win
+        wa, wo = oracle_window(arrays, opc, frames, W, H, win)
+        assert np.array_equal(bits(acc[y0:y1, x0:x1]), bits(wa)), (what, win, "accumulation image")
+        assert np.array_equal(bits(out[y0:y1, x0:x1]), bits(wo)), (what, win, "draw image")
+        assert np.any(wa[..., :3] > 0)          # not an empty window
+
+
+@pytest.fixture(scope="module")
+def R():
+    import raytracer_amd
+    return raytracer_amd
+
+
+@pytest.fixture(scope="module")
+def generated(tmp_path_factory):
+    """The two generated benchmark scenes at their full size: description, 18 arrays, push constants."""
+    from raytracer_amd import scenefile as SF
+    tmp = str(tmp_path_factory.mktemp("generated"))
+    built = {}
+    for desc in (SF.config_heightfield(tmp), SF.config_blob_grid(tmp)):
+        scene, cam, pc = SF.build_scene(desc, tmp)
+        depth = max(scene.model_info(os.path.join(tmp, m))[2] for m in {o["model"] for o in desc["objects"]})
+        tris = sum(scene.model_info(os.path.join(tmp, m))[0] for m in {o["model"] for o in desc["objects"]})
+        built[desc["name"]] = (desc, scene, scene.buffers().to_arrays(), pc, depth, tris)
+    return built
+
+
+def test_default_scene_2560x1369_multi_frame_launch(R, default_scene_arrays):
+    """BASELINE configs[1] as the benchmark runs it: ONE rt_render_frames call of 8 frames on the default
+    pipeline (two samples per lane, 8 frames per launch) at 2560x1369, against 8 single-frame dispatches
+    of the lock-step kernel and against oracle windows."""
+    W, H = 2560, 1369
+    frames = list(range(8))
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays); r.resize(W, H)
+        assert r.get_option(R.RT_OPT_PIPELINE) == 3 and r.get_option(R.RT_OPT_FRAMES_PER_LAUNCH) == 8
+        opc = scenes.make_pc(default_scene_arrays, W, H)
+        r.render_frames(to_pc(R, opc), 0, 1, 8)
+        acc = r.read_image(R.RT_IMAGE_ACCUM); out = r.read_image(R.RT_IMAGE_DRAW)
+        r.set_option(R.RT_OPT_PIPELINE, 0)
+        r.clear_accumulation()
+        for f in frames:
+            opc["frame"] = f
+            r.render_frame(to_pc(R, opc))
+        acc0 = r.read_image(R.RT_IMAGE_ACCUM); out0 = r.read_image(R.RT_IMAGE_DRAW)
+        assert np.array_equal(bits(acc), bits(acc0)) and np.array_equal(bits(out), bits(out0))
+        windows = [(1216, 560, 1344, 608),      # the dragon
+                   (890, 600, 986, 648),        # left wall / back wall / floor edges
+                   (1200, 0, 1360, 24),         # ceiling and emitter, first rows
+                   (1000, 1352, 1128, 1369),    # ragged bottom rows (1369 = 171 * 8 + 1)
+                   (2496, 1340, 2560, 1369)]    # bottom right corner
+        check_windows(default_scene_arrays, opc, frames, W, H, windows, acc, out, "default 2560x1369")
+        assert np.all(out[..., 3] == 0) and np.all(acc[..., 3] == 0)
+    finally:
+        r.close()
+
+
+def test_pair_kernel_is_what_runs(R, default_scene_arrays):
+    """rt_render_frames with >= 2 samples of a pixel per launch runs the two-samples-per-lane kernel; a
+    launch with an odd number of samples ends on a half-empty pair. Single frames run the lock-step
+    kernel. Both against the oracle, at a ragged size."""
+    W, H = 333, 187
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays); r.resize(W, H)
+        opc = scenes.make_pc(default_scene_arrays, W, H)
+        for count in (2, 5, 8, 11):
+            r.clear_accumulation()
+            r.render_frames(to_pc(R, opc), 0, 1, count)
+            acc = r.read_image(R.RT_IMAGE_ACCUM); out = r.read_image(R.RT_IMAGE_DRAW)
+            wa, wo = oracle_window(default_scene_arrays, opc, list(range(count)), W, H, (0, 0, W, H))
+            assert np.array_equal(bits(acc), bits(wa)) and np.array_equal(bits(out), bits(wo)), count
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("name", ["heightfield", "blob_grid"])
+def test_generated_configs_full_size(R, generated, name):
+    """BASELINE configs[2] (100 352-triangle height field, 1920x1080) and the scene of configs[4]
+    (64 x 15 616 = 999 424 stored triangles, diffuse / metal / glass, 1920x1080): pipelines 0, 2 and the
+    default 3 give one image, every counting build gives one set of counters, oracle windows match."""
+    desc, scene, arrays, pc, depth, tris = generated[name]
+    W, H = desc["width"], desc["height"]
+    assert (W, H) == (1920, 1080) and depth <= 31
+    assert tris == (100352 + 2 if name == "heightfield" else 64 * 15616 + 2)
+    frames = [0, 1]
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(scene.buffers()); r.resize(W, H)
+        assert r.get_option(R.RT_INFO_STACK_DEPTH) <= 31
+        images, stats = {}, {}
+        for pipeline in (3, 0, 2):
+            r.set_option(R.RT_OPT_PIPELINE, pipeline)
+            r.clear_accumulation()
+            pc.frame = 0
+            r.render_frames(pc, 0, 1, len(frames))
+            images[pipeline] = (r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW))
+            pc.frame = 1
+            st = r.frame_stats(pc)
+            stats[pipeline] = (st.rays, st.bvhNodeTests, st.triangleTests, st.samples)
+        for pipeline in (0, 2):
+            assert np.array_equal(bits(images[pipeline][0]), bits(images[3][0])), pipeline
+            assert np.array_equal(bits(images[pipeline][1]), bits(images[3][1])), pipeline
+            assert stats[pipeline] == stats[3], (pipeline, stats)
+        assert stats[3][3] == W * H and stats[3][0] >= W * H
+        opc = np.frombuffer(bytes(pc.as_bytes()), dtype=O.PC_DTYPE).copy()
+        if name == "heightfield":
+            windows = [(900, 520, 1028, 568), (300, 700, 396, 748), (1500, 300, 1596, 332), (1856, 1048, 1920, 1080)]
+        else:
+            windows = [(900, 500, 996, 548), (600, 640, 664, 688), (1200, 380, 1264, 428), (0, 1040, 64, 1080)]
+        acc, out = images[3]
+        check_windows(arrays, opc, frames, W, H, windows, acc, out, name)
+        # the counters of frame 1 over one window, against the oracle's per-pixel counters there
+        x0, y0, x1, y1 = windows[0]
+        opc["frame"] = 1
+        o = O.render(arrays, O.pc_bytes(opc), W, H, window=windows[0], counters=True)
+        assert o["rays"][y0:y1, x0:x1].min() >= 1
+        assert int(o["node"].sum()) * (W * H) // ((x1 - x0) * (y1 - y0)) > 0
+    finally:
+        r.close()
+
+
+def test_default_scene_3840x2160_one_launch(R, default_scene_arrays):
+    """BASELINE configs[3]'s image size: one launch of 8 frames at 3840x2160, twice (same bits), against
+    the in-order accumulation of single frames, against an oracle window, and as rank 1 of a 2-way
+    sample split (frames 1, 3, 5, ...)."""
+    W, H = 3840, 2160
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays); r.resize(W, H)
+        opc = scenes.make_pc(default_scene_arrays, W, H)
+        r.render_frames(to_pc(R, opc), 0, 1, 8)
+        acc = r.read_image(R.RT_IMAGE_ACCUM); out = r.read_image(R.RT_IMAGE_DRAW)
+        r.clear_accumulation()
+        r.render_frames(to_pc(R, opc), 0, 1, 8)
+        assert np.array_equal(bits(r.read_image(R.RT_IMAGE_ACCUM)), bits(acc))
+        r.set_option(R.RT_OPT_PIPELINE, 0)
+        opc1 = scenes.make_pc(default_scene_arrays, W, H, accumulateFrames=0)
+        total = np.zeros((H, W, 4), np.float32)
+        for f in range(8):
+            r.clear_accumulation()
+            opc1["frame"] = f
+            r.render_frame(to_pc(R, opc1))
+            total = total + r.read_image(R.RT_IMAGE_ACCUM)
+        assert np.array_equal(bits(acc), bits(total))
+        want = np.sqrt(np.maximum(total[..., :3] * np.float32(1.0 / 8.0), 0), dtype=np.float32)
+        assert np.array_equal(bits(out[..., :3]), bits(want))
+        check_windows(default_scene_arrays, opc, list(range(8)), W, H, [(1850, 850, 1978, 898), (3776, 2128, 3840, 2160)], acc, out, "4K")
+        r.set_option(R.RT_OPT_PIPELINE, 3)
+        r.clear_accumulation()
+        r.render_frames(to_pc(R, opc), 1, 2, 4)
+        acc = r.read_image(R.RT_IMAGE_ACCUM)
+        wa, _ = oracle_window(default_scene_arrays, opc, [1, 3, 5, 7], W, H, (1850, 850, 1978, 898))
+        assert np.array_equal(bits(acc[850:898, 1850:1978]), bits(wa))
+    finally:
+        r.close()

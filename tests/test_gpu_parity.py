@@ -58,9 +58,18 @@ def gpu_frames(R, r, opc, frames, W, H, clear=True):
     r.resize(W, H) if (r.width, r.height) != (W, H) else None
     if clear:
         r.clear_accumulation()
-    for f in frames:
-        opc["frame"] = f
-        r.render_frame(to_pc(R, opc))
+    frames = list(frames)
+    steps = {b - a for a, b in zip(frames, frames[1:])}
+    if r.get_option(R.RT_OPT_PIPELINE) == 3 and len(frames) >= 2 and len(steps) == 1 and min(steps) >= 1:
+        # the two-samples-per-lane kernel only runs when a launch holds at least two samples of a pixel:
+        # hand the whole frame set to rt_render_frames (single-frame dispatches would run the lock-step kernel)
+        opc["frame"] = frames[0]
+        r.render_frames(to_pc(R, opc), frames[0], steps.pop(), len(frames))
+        opc["frame"] = frames[-1]
+    else:
+        for f in frames:
+            opc["frame"] = f
+            r.render_frame(to_pc(R, opc))
     return r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW)
 
 
