@@ -97,10 +97,26 @@ enum {
      * frame of a launch only. Saves the launch ramps and draw-image writes. Default 8; 1 = one launch per
      * frame. rt_render_frame (one frame) is not affected. */
     RT_OPT_FRAMES_PER_LAUNCH = 16,
+    /* Traversal of the BVH parents by the lock-step kernels (pipelines 0 and 3) in path-tracing mode.
+     * 0 (default) = the reference's trees in the reference's order (left child first,
+     * raytrace.comp:603-604): results bit-identical to the CPU oracle. 1 = near-first: every object whose
+     * transform shrinks nothing walks a tree rebuilt at first use (binned surface-area heuristic, tight
+     * boxes, at most RT_OPT_SAH_MAX_LEAF triangles per leaf, default 4), the nearer child first, children
+     * behind the closest hit dropped; every object gets a tight world box. The hit GetHit returns is the
+     * triangle with the smallest world-space distance in either order, so the images differ only where two
+     * triangles tie exactly (shared edges): within the stated tolerance (>= 99.5 % of pixels within
+     * 1e-4 + 1e-4*|ref| at 1 spp, PSNR >= 45 dB converged), not bit for bit. Objects scaled below 1 keep
+     * the reference's tree and order (their result depends on it, raytrace.comp:553-572). The counting
+     * builds, the debug views, pipelines 1 and 2 and dispatches with parentBVHCount below the uploaded
+     * object count always use 0. */
+    RT_OPT_TRAVERSAL = 17, RT_OPT_SAH_MAX_LEAF = 18,
     /* Read-only (rt_get_option) facts about the uploaded scene: traversal stack entries a lane can
      * need (longest chain of two-child records), number of two-child records, and number of
      * triangle records in leaf order (a triangle that several leaves share counts once per leaf). */
-    RT_INFO_STACK_DEPTH = 100, RT_INFO_RECORDS = 101, RT_INFO_TRIANGLES = 102
+    RT_INFO_STACK_DEPTH = 100, RT_INFO_RECORDS = 101, RT_INFO_TRIANGLES = 102,
+    /* The same for the near-first scene (built on first use): objects that walk a rebuilt tree, two-child
+     * records and triangle records in its arrays, traversal stack entries. */
+    RT_INFO_FAST_OBJECTS = 103, RT_INFO_FAST_RECORDS = 104, RT_INFO_FAST_TRIANGLES = 105, RT_INFO_FAST_STACK_DEPTH = 106
 };
 
 /* ---- device context ------------------------------------------------------ */

@@ -1,0 +1,203 @@
+// rt_bvh.cpp - a second bounding-volume hierarchy per model, built at upload time for the
+// "near-first" traversal (RT_OPT_TRAVERSAL = 1).
+//
+// The reference walks its midpoint-split tree in one fixed order (left child first,
+// raytrace.comp:603-604) and carries a TODO for visiting the nearer child first
+// (raytrace.comp:578-601); its surface-area-heuristic builder (ModelLoader.cpp:124-260) is unfinished
+// and never called. This file is the build's own take on both: a binned SAH builder over the
+// triangle records of one model, producing the same two-child 64-byte records and leaf runs the
+// kernels already walk, with tight boxes. The kernels then enter the nearer child first and drop
+// every child whose entry distance is not inside the closest hit so far.
+//
+// Which objects may use it. GetHit accepts a triangle when its object-space hitT AND its world-space
+// distance lie inside (tMin, closestSoFar), closestSoFar being a world-space distance
+// (raytrace.comp:553-572). For an object whose transform does not shrink anything (every singular
+// value of the model matrix >= 1) the object-space distance is never larger than the world-space one,
+// the first test is implied by the second, and the accepted hit is the triangle with the smallest
+// world-space distance whatever the visiting order - only exact ties can fall the other way. For an
+// object scaled below 1 the first test does bite and the result depends on the order, so such
+// objects keep the reference's tree and order (rt_host.cpp decides per object).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "rt_device.h"
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void clear() { for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; } }
+    void grow(const float p[3]) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    void grow(const Box& b) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    float area() const
+    {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return (dx < 0.0f || dy < 0.0f || dz < 0.0f) ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct Prim { Box b; float c[3]; uint32_t src; };
+
+struct Builder {
+    const DevTri* src;
+    std::vector<Prim> prims;
+    std::vector<DevNode>* nodes;
+    std::vector<DevTri>* tris;
+    int maxLeaf;
+    int maxDepth = 0;
+    static const int kBins = 16;
+
+    // The boxes of the records are what the slab test sees; the triangle test works on v0/e1/e2. Pad
+    // every triangle's box by a few units in the last place of its largest coordinate so that a hit
+    // the triangle test accepts right at a vertex or edge is not cut off by a box that is exactly tight.
+    static Box triBox(const DevTri& t)
+    {
+        Box b; b.clear();
+        float v1[3], v2[3];
+        for (int a = 0; a < 3; ++a) { v1[a] = t.v0[a] + t.e1[a]; v2[a] = t.v0[a] + t.e2[a]; }
+        b.grow(t.v0); b.grow(v1); b.grow(v2);
+        for (int a = 0; a < 3; ++a) {
+            const float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+            const float pad = std::max(m * 4e-6f, 1e-7f);
+            b.lo[a] -= pad; b.hi[a] += pad;
+        }
+        return b;
+    }
+
+    int32_t makeLeaf(size_t begin, size_t end)
+    {
+        const size_t base = tris->size();
+        for (size_t i = begin; i < end; ++i) {
+            DevTri t = src[prims[i].src];
+            t.remaining = (int32_t)(end - i);
+            tris->push_back(t);
+        }
+        return ~(int32_t)base;
+    }
+
+    static int log2ceil(size_t n) { int k = 0; while (((size_t)1 << k) < n) ++k; return k; }
+
+    // Builds [begin, end) and returns its reference; `depth` = number of records on the path from the
+    // root down to and including the record this call may create.
+    int32_t build(size_t begin, size_t end, int depth, Box& bounds)
+    {
+        bounds.clear();
+        Box cb; cb.clear();
+        for (size_t i = begin; i < end; ++i) { bounds.grow(prims[i].b); cb.grow(prims[i].c); }
+        const size_t n = end - begin;
+        if (n <= 2 && n <= (size_t)maxLeaf) return makeLeaf(begin, end);
+        if (n == 1) return makeLeaf(begin, end);
+
+        // no room left for an unbalanced tree below this point: split by count (depth stays within the
+        // kernels' 32-entry traversal stack)
+        const bool forceMedian = depth + log2ceil(n) + 1 >= RT_MAX_STACK - 1;
+        size_t mid = begin;
+        bool haveSplit = false;
+        if (!forceMedian) {
+            float bestCost = INFINITY;
+            int bestAxis = -1, bestBin = -1;
+            for (int a = 0; a < 3; ++a) {
+                const float ext = cb.hi[a] - cb.lo[a];
+                if (!(ext > 0.0f)) continue;
+                Box bb[kBins]; size_t cnt[kBins];
+                for (int k = 0; k < kBins; ++k) { bb[k].clear(); cnt[k] = 0; }
+                const float scale = (float)kBins / ext;
+                for (size_t i = begin; i < end; ++i) {
+                    int k = (int)((prims[i].c[a] - cb.lo[a]) * scale);
+                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    bb[k].grow(prims[i].b); cnt[k]++;
+                }
+                float rightArea[kBins]; size_t rightCnt[kBins];
+                Box acc; acc.clear(); size_t c = 0;
+                for (int k = kBins - 1; k > 0; --k) { acc.grow(bb[k]); c += cnt[k]; rightArea[k] = acc.area(); rightCnt[k] = c; }
+                acc.clear(); c = 0;
+                for (int k = 0; k < kBins - 1; ++k) {
+                    acc.grow(bb[k]); c += cnt[k];
+                    if (c == 0 || rightCnt[k + 1] == 0) continue;
+                    const float cost = acc.area() * (float)c + rightArea[k + 1] * (float)rightCnt[k + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = k; }
+                }
+            }
+            if (bestAxis >= 0) {
+                const float parentArea = std::max(bounds.area(), 1e-30f);
+                const float splitCost = 1.0f + bestCost / parentArea;     // one record visit + expected triangle tests below
+                if (n <= (size_t)maxLeaf && (float)n <= splitCost) return makeLeaf(begin, end);
+                const float ext = cb.hi[bestAxis] - cb.lo[bestAxis];
+                const float scale = (float)kBins / ext;
+                const float lo = cb.lo[bestAxis];
+                auto it = std::partition(prims.begin() + begin, prims.begin() + end, [&](const Prim& p) {
+                    int k = (int)((p.c[bestAxis] - lo) * scale);
+                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    return k <= bestBin;
+                });
+                mid = (size_t)(it - prims.begin());
+                haveSplit = mid > begin && mid < end;
+            }
+        }
+        if (!haveSplit) {
+            // all centroids in one place, or the depth guard: halve by count along the widest axis
+            if (!forceMedian && n <= (size_t)std::max(maxLeaf, 8)) return makeLeaf(begin, end);
+            int a = 0;
+            for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[a] - cb.lo[a]) a = k;
+            mid = begin + n / 2;
+            std::nth_element(prims.begin() + begin, prims.begin() + mid, prims.begin() + end,
+                             [a](const Prim& x, const Prim& y) { return x.c[a] < y.c[a]; });
+        }
+
+        const int32_t idx = (int32_t)nodes->size();
+        nodes->push_back(DevNode{});
+        maxDepth = std::max(maxDepth, depth);
+        Box bl, br;
+        const int32_t rl = build(begin, mid, depth + 1, bl);
+        const int32_t rr = build(mid, end, depth + 1, br);
+        DevNode nd{};
+        for (int a = 0; a < 3; ++a) {
+            nd.lo[a][0] = bl.lo[a]; nd.hi[a][0] = bl.hi[a];
+            nd.lo[a][1] = br.lo[a]; nd.hi[a][1] = br.hi[a];
+        }
+        nd.first = rl;
+        nd.second = rr;
+        (*nodes)[idx] = nd;
+        return idx;
+    }
+};
+
+} // namespace
+
+// Builds a SAH tree over `count` triangle records (object space). New two-child records are appended to
+// `nodes`, the leaves' triangle records (copies of the input records, regrouped) to `tris`; references
+// are indices into those vectors (record index, or ~first triangle for a leaf). Returns the root
+// reference, the tight bounds of the model and the number of traversal-stack entries a lane can need.
+int32_t rt_build_sah(const DevTri* src, size_t count, int maxLeaf, std::vector<DevNode>& nodes, std::vector<DevTri>& tris,
+                     float boundsLo[3], float boundsHi[3], int& depth)
+{
+    Builder b;
+    b.src = src;
+    b.nodes = &nodes;
+    b.tris = &tris;
+    b.maxLeaf = std::max(1, maxLeaf);
+    b.prims.resize(count);
+    for (size_t i = 0; i < count; ++i) {
+        Prim& p = b.prims[i];
+        p.b = Builder::triBox(src[i]);
+        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]);
+        p.src = (uint32_t)i;
+    }
+    Box bounds; bounds.clear();
+    int32_t root = RT_REF_EMPTY;
+    if (count > 0) root = b.build(0, count, 1, bounds);
+    for (int a = 0; a < 3; ++a) { boundsLo[a] = bounds.lo[a]; boundsHi[a] = bounds.hi[a]; }
+    depth = b.maxDepth;
+    return root;
+}
+
+// Bounds of `count` triangle records, padded like the boxes of the rebuilt trees.
+void rt_triangle_bounds(const DevTri* src, size_t count, float boundsLo[3], float boundsHi[3])
+{
+    Box bounds; bounds.clear();
+    for (size_t i = 0; i < count; ++i) bounds.grow(Builder::triBox(src[i]));
+    for (int a = 0; a < 3; ++a) { boundsLo[a] = bounds.lo[a]; boundsHi[a] = bounds.hi[a]; }
+}

@@ -82,6 +82,10 @@ struct DevScene {
     int32_t            anyLeafCount;
     int32_t            objectCount;   /* number of DevObject records uploaded */
     int32_t            stackDepth;    /* entries of traversal stack a lane can need (<= RT_MAX_STACK) */
+    /* Two-child records with an index >= nearFirstBase belong to trees rebuilt at upload (rt_bvh.cpp):
+     * inside an object whose root is such a record the walk enters the nearer child first. INT32_MAX
+     * in the reference-order scene. */
+    int32_t            nearFirstBase;
 };
 
 struct DevLaunch {

@@ -26,6 +26,9 @@
 #include "rt_device.h"
 
 void rt_mat4_inverse(const float in[16], float out[16]);   // rt_scene.cpp
+int32_t rt_build_sah(const DevTri* src, size_t count, int maxLeaf, std::vector<DevNode>& nodes, std::vector<DevTri>& tris,
+                     float boundsLo[3], float boundsHi[3], int& depth);   // rt_bvh.cpp
+void rt_triangle_bounds(const DevTri* src, size_t count, float boundsLo[3], float boundsHi[3]);   // rt_bvh.cpp
 
 extern "C" {
 hipError_t rt_launch_megakernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
@@ -74,6 +77,24 @@ struct rt_ctx {
     bool haveScene = false;
     size_t sceneBytes = 0;
     size_t nodeCount = 0, triCount = 0;
+
+    // host copies of the re-laid-out scene (the caller's arrays may be gone after rt_upload_scene) and the
+    // near-first scene built from them on first use (RT_OPT_TRAVERSAL = 1): its own object records
+    // (tight world boxes, roots in the rebuilt trees), and record / triangle arrays that hold the
+    // rebuilt trees (behind a copy of the reference-order records when some object has to keep those)
+    std::vector<DevObject> hObjects;
+    std::vector<DevNode> hNodes;
+    std::vector<DevTri> hTris;
+    int hStackDepth = 0;
+    DevScene fastScene{};
+    void* dFastObjects = nullptr;
+    void* dFastNodes = nullptr;
+    void* dFastTris = nullptr;
+    void* dFastAnyOrder = nullptr;
+    bool haveFast = false;
+    int fastObjects = 0;          // objects that walk a rebuilt tree
+    size_t fastNodeCount = 0, fastTriCount = 0;
+    int optTraversal = 0, sahMaxLeaf = 4;
 
     // images
     int width = 0, height = 0;
@@ -126,8 +147,20 @@ int failHip(rt_ctx* ctx, hipError_t e, const char* what)
         if (e_ != hipSuccess) return failHip(ctx, e_, #call);     \
     } while (0)
 
+void freeFastScene(rt_ctx* c)
+{
+    for (void** p : { &c->dFastObjects, &c->dFastNodes, &c->dFastTris, &c->dFastAnyOrder }) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    c->haveFast = false;
+    c->fastObjects = 0;
+    c->fastNodeCount = c->fastTriCount = 0;
+}
+
 void freeScene(rt_ctx* c)
 {
+    freeFastScene(c);
     for (void** p : { &c->dObjects, &c->dNodes, &c->dTris, &c->dNrms, &c->dMaterials, &c->dAnyOrder }) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -328,6 +361,170 @@ int uploadArray(rt_ctx* ctx, void** dst, const void* src, size_t bytes)
     return RT_OK;
 }
 
+// Order in which "any hit" rays visit the objects: leaf parents (a handful of triangles, no walk)
+// before BVH parents; both groups keep their scene order. Layout: anyOrder[P], pad, nextAny[P + 1].
+std::vector<int32_t> orderTables(const std::vector<DevObject>& objects, int32_t& anyFirst, int32_t& leafCount)
+{
+    const int32_t P = (int32_t)objects.size();
+    std::vector<int32_t> anyOrder, tables(2 * (size_t)P + 2, P);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int32_t i = 0; i < P; ++i)
+            if ((objects[i].root >= 0) == (pass == 1)) anyOrder.push_back(i);
+    for (int32_t p = 0; p < P; ++p) {
+        tables[p] = anyOrder[p];                                         // anyOrder
+        tables[P + 1 + anyOrder[p]] = p + 1 < P ? anyOrder[p + 1] : P;   // nextAny
+    }
+    anyFirst = P > 0 ? anyOrder[0] : 0;
+    leafCount = 0;
+    for (int32_t i = 0; i < P; ++i) leafCount += objects[i].root < 0 ? 1 : 0;
+    return tables;
+}
+
+// Largest singular value of the 3x3 linear part of a row-major 3x4 matrix: the square root of the
+// largest eigenvalue of A^T A (closed form for a symmetric 3x3 matrix).
+double largestSingularValue(const float m[12])
+{
+    double a[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+            for (int k = 0; k < 3; ++k) v += (double)m[4 * k + i] * (double)m[4 * k + j];
+            a[i][j] = v;
+        }
+    const double p1 = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    const double q = (a[0][0] + a[1][1] + a[2][2]) / 3.0;
+    if (p1 <= 1e-300) return std::sqrt(std::max(0.0, std::max(a[0][0], std::max(a[1][1], a[2][2]))));
+    const double p2 = (a[0][0] - q) * (a[0][0] - q) + (a[1][1] - q) * (a[1][1] - q) + (a[2][2] - q) * (a[2][2] - q) + 2.0 * p1;
+    const double p = std::sqrt(p2 / 6.0);
+    double b[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) b[i][j] = (a[i][j] - (i == j ? q : 0.0)) / p;
+    const double det = b[0][0] * (b[1][1] * b[2][2] - b[1][2] * b[2][1]) - b[0][1] * (b[1][0] * b[2][2] - b[1][2] * b[2][0]) +
+                       b[0][2] * (b[1][0] * b[2][1] - b[1][1] * b[2][0]);
+    const double r = std::max(-1.0, std::min(1.0, det / 2.0));
+    const double eig = q + 2.0 * p * std::cos(std::acos(r) / 3.0);
+    return std::sqrt(std::max(0.0, eig));
+}
+
+// Triangle records an object's reference tree can reach, in the reference's visiting order. A child
+// whose box is inverted is marked dead at upload; one whose box has no thickness on some axis can
+// not be entered either (IntersectAABB fails on `t.max <= t.min`, raytrace.comp:239), so neither
+// contributes triangles.
+void gatherTriangles(const rt_ctx* c, int32_t root, std::vector<DevTri>& out)
+{
+    std::vector<int32_t> stack{ root };
+    while (!stack.empty()) {
+        const int32_t ref = stack.back();
+        stack.pop_back();
+        if (!(ref > RT_REF_LIVE_MIN)) continue;
+        if (ref < 0) {
+            for (size_t k = (size_t)~ref; k < c->hTris.size(); ++k) {
+                out.push_back(c->hTris[k]);
+                if (c->hTris[k].remaining <= 1) break;
+            }
+            continue;
+        }
+        const DevNode& n = c->hNodes[(size_t)ref];
+        auto enterable = [&](int ch) { return n.lo[0][ch] < n.hi[0][ch] && n.lo[1][ch] < n.hi[1][ch] && n.lo[2][ch] < n.hi[2][ch]; };
+        if (enterable(1)) stack.push_back(n.second);
+        if (enterable(0)) stack.push_back(n.first);
+    }
+}
+
+// Builds and uploads the near-first scene (see rt_ctx) from the host copies of the uploaded scene.
+int ensureFastScene(rt_ctx* ctx)
+{
+    if (ctx->haveFast) return RT_OK;
+    const size_t P = ctx->hObjects.size();
+    std::vector<DevObject> objects = ctx->hObjects;
+    // an object may walk a rebuilt tree when its transform shrinks nothing: every singular value of the
+    // model matrix >= 1, i.e. the largest singular value of inverseTransform <= 1 (rt_bvh.cpp)
+    std::vector<char> eligible(P, 0);
+    bool keepReference = false;
+    for (size_t i = 0; i < P; ++i) {
+        eligible[i] = largestSingularValue(objects[i].inv) <= 1.0 + 1e-5;
+        if (!eligible[i] && objects[i].root >= 0) keepReference = true;
+    }
+    std::vector<DevNode> nodes;
+    std::vector<DevTri> tris;
+    // every object keeps its leaf runs in the reference arrays unless it gets a rebuilt tree, so the
+    // reference triangle records always come along; the reference two-child records only when needed
+    tris = ctx->hTris;
+    if (keepReference) nodes = ctx->hNodes;
+    const int32_t nearFirstBase = (int32_t)nodes.size();
+    struct Built { int32_t root; float lo[3], hi[3]; int depth; };
+    // (reference root, rebuilt?) -> tree and tight bounds; instances of one model share an entry
+    std::map<std::pair<int32_t, bool>, Built> memo;
+    int depth = keepReference ? ctx->hStackDepth : 1;
+    int rebuilt = 0;
+    for (size_t i = 0; i < P; ++i) {
+        DevObject& o = objects[i];
+        if (!(o.root > RT_REF_LIVE_MIN)) continue;
+        const bool rebuild = o.root >= 0 && eligible[i];
+        auto key = std::make_pair(o.root, rebuild);
+        auto it = memo.find(key);
+        if (it == memo.end()) {
+            std::vector<DevTri> src;
+            gatherTriangles(ctx, o.root, src);
+            Built b{};
+            b.root = o.root;      // keeps its reference tree (or is a single leaf): only the tight bounds are taken
+            if (src.empty()) b.root = RT_REF_EMPTY;
+            else if (rebuild) b.root = rt_build_sah(src.data(), src.size(), ctx->sahMaxLeaf, nodes, tris, b.lo, b.hi, b.depth);
+            else rt_triangle_bounds(src.data(), src.size(), b.lo, b.hi);
+            it = memo.emplace(key, b).first;
+        }
+        const Built& b = it->second;
+        if (rebuild && b.root != RT_REF_EMPTY) { rebuilt++; depth = std::max(depth, b.depth); }
+        o.root = b.root;
+        if (b.root == RT_REF_EMPTY) { o.root = RT_REF_EMPTY; continue; }
+        // tight world box: the 8 corners of the model's tight bounds through the model matrix, padded
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (int corner = 0; corner < 8; ++corner) {
+            const float x = (corner & 1) ? b.hi[0] : b.lo[0], y = (corner & 2) ? b.hi[1] : b.lo[1], z = (corner & 4) ? b.hi[2] : b.lo[2];
+            for (int r = 0; r < 3; ++r) {
+                const float w = (o.fwd[4 * r + 0] * x + o.fwd[4 * r + 1] * y) + (o.fwd[4 * r + 2] * z + o.fwd[4 * r + 3]);
+                lo[r] = std::min(lo[r], w); hi[r] = std::max(hi[r], w);
+            }
+        }
+        for (int r = 0; r < 3; ++r) {
+            const float pad = std::max(std::max(std::fabs(lo[r]), std::fabs(hi[r])) * 1e-5f, 1e-6f);
+            // never larger than the reference's own box
+            o.bmin[r] = std::max(o.bmin[r], lo[r] - pad);
+            o.bmax[r] = std::min(o.bmax[r], hi[r] + pad);
+        }
+        if (o.bmin[0] > o.bmax[0] || o.bmin[1] > o.bmax[1] || o.bmin[2] > o.bmax[2]) o.root = RT_REF_DEAD;
+    }
+    if (depth > RT_MAX_STACK) return fail(ctx, RT_ERR_UNSUPPORTED, "rebuilt tree deeper than the traversal stack");
+
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    freeFastScene(ctx);
+    int32_t anyFirst = 0, leafCount = 0;
+    const std::vector<int32_t> tables = orderTables(objects, anyFirst, leafCount);
+    int rc;
+    if ((rc = uploadArray(ctx, &ctx->dFastObjects, objects.data(), objects.size() * sizeof(DevObject))) != RT_OK) return rc;
+    if ((rc = uploadArray(ctx, &ctx->dFastNodes, nodes.data(), nodes.size() * sizeof(DevNode))) != RT_OK) return rc;
+    if ((rc = uploadArray(ctx, &ctx->dFastTris, tris.data(), tris.size() * sizeof(DevTri))) != RT_OK) return rc;
+    if ((rc = uploadArray(ctx, &ctx->dFastAnyOrder, tables.data(), tables.size() * sizeof(int32_t))) != RT_OK) return rc;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die at return
+    DevScene f = ctx->scene;
+    f.objects = static_cast<const DevObject*>(ctx->dFastObjects);
+    f.nodes = static_cast<const DevNode*>(ctx->dFastNodes);
+    f.tris = static_cast<const DevTri*>(ctx->dFastTris);
+    f.anyOrder = static_cast<const int32_t*>(ctx->dFastAnyOrder);
+    f.nextAny = static_cast<const int32_t*>(ctx->dFastAnyOrder) + P + 1;
+    f.anyFirst = anyFirst;
+    f.anyLeafCount = leafCount;
+    f.stackDepth = std::max(1, std::min(RT_MAX_STACK, depth));
+    f.nearFirstBase = nearFirstBase;
+    ctx->fastScene = f;
+    ctx->fastObjects = rebuilt;
+    ctx->fastNodeCount = nodes.size();
+    ctx->fastTriCount = tris.size();
+    ctx->haveFast = true;
+    return RT_OK;
+}
+
 DevLaunch makeLaunch(const rt_ctx* c)
 {
     DevLaunch L{};
@@ -462,6 +659,15 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
     const bool countBuild = statsOnly || pc.renderMode == 3 || pc.renderMode == 4;
     const bool pathTrace = pc.renderMode == 0 || pc.renderMode == 3 || pc.renderMode == 4;
     hipError_t e;
+    // near-first traversal: path tracing on the lock-step kernels only; the counting builds and the debug
+    // views always walk the reference's trees in the reference's order
+    const DevScene* scene = &ctx->scene;
+    if (ctx->optTraversal == 1 && (ctx->optPipeline == 0 || ctx->optPipeline == 3) && pc.renderMode == 0 && !statsOnly &&
+        pc.parentBVHCount == ctx->scene.objectCount) {
+        int rc = ensureFastScene(ctx);
+        if (rc != RT_OK) return rc;
+        scene = &ctx->fastScene;
+    }
     if (ctx->optPipeline == 2 && pathTrace && pc.raysPerPixel >= 1 && ctx->scene.objectCount < 65535)   // object indices are packed in 16 bits
         return launchWavefront(ctx, pc, L, statsOnly, countBuild, first, last);
     if (ctx->optPipeline == 1 && pathTrace && pc.raysPerPixel >= 1) {
@@ -474,11 +680,11 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
                statsOnly ? 1 : 0, ctx->dQueue, blocks, ctx->stream, diag);
     } else if (ctx->optPipeline == 3 && pc.renderMode == 0 && !statsOnly && pc.raysPerPixel >= 1 && (long long)frames * pc.raysPerPixel >= 2) {
         auto fn = ctx->optFast ? rt_launch_pairkernel_fast : rt_launch_pairkernel_strict;
-        e = fn(&ctx->scene, &pc, &L, ctx->accum, ctx->draw, ctx->stream);
+        e = fn(scene, &pc, &L, ctx->accum, ctx->draw, ctx->stream);
     } else {
         // the depth / box views and the degenerate raysPerPixel <= 0 case stay on the lock-step kernel
         auto fn = ctx->optFast ? rt_launch_megakernel_fast : rt_launch_megakernel_strict;
-        e = fn(&ctx->scene, &pc, &L, ctx->accum, ctx->draw, statsOnly ? ctx->dCounters : nullptr, countBuild ? 1 : 0,
+        e = fn(scene, &pc, &L, ctx->accum, ctx->draw, statsOnly ? ctx->dCounters : nullptr, countBuild ? 1 : 0,
                statsOnly ? 1 : 0, ctx->stream);
     }
     if (e != hipSuccess) return failHip(ctx, e, "kernel launch");
@@ -584,6 +790,19 @@ int rt_set_option(rt_ctx* ctx, int option, int value)
         if (value < 1 || value > 4096) return fail(ctx, RT_ERR_INVALID_ARG, "frames per launch must be in [1,4096]");
         ctx->framesPerLaunch = value;
         return RT_OK;
+    case RT_OPT_TRAVERSAL:
+        if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID_ARG, "traversal must be 0 (reference order) or 1 (near-first on rebuilt trees)");
+        ctx->optTraversal = value;
+        return RT_OK;
+    case RT_OPT_SAH_MAX_LEAF:
+        if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARG, "triangles per rebuilt leaf must be in [1,64]");
+        if (value != ctx->sahMaxLeaf) {
+            RT_HIP(ctx, hipSetDevice(ctx->device));
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            freeFastScene(ctx);
+        }
+        ctx->sahMaxLeaf = value;
+        return RT_OK;
     case RT_OPT_WF_REFILL:
         if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront refill threshold must be in [1,64]");
         ctx->wfRefill = value;
@@ -616,6 +835,17 @@ int rt_get_option(rt_ctx* ctx, int option, int* value)
     case RT_OPT_WF_WALK_WAVES: *value = ctx->wfWalkWaves; return RT_OK;
     case RT_OPT_WF_PARTS: *value = ctx->wfParts; return RT_OK;
     case RT_OPT_FRAMES_PER_LAUNCH: *value = ctx->framesPerLaunch; return RT_OK;
+    case RT_OPT_TRAVERSAL: *value = ctx->optTraversal; return RT_OK;
+    case RT_OPT_SAH_MAX_LEAF: *value = ctx->sahMaxLeaf; return RT_OK;
+    case RT_INFO_FAST_OBJECTS: case RT_INFO_FAST_RECORDS: case RT_INFO_FAST_TRIANGLES: case RT_INFO_FAST_STACK_DEPTH: {
+        if (!ctx->haveScene) { *value = 0; return RT_OK; }
+        int rc = ensureFastScene(ctx);
+        if (rc != RT_OK) return rc;
+        *value = option == RT_INFO_FAST_OBJECTS ? ctx->fastObjects
+               : option == RT_INFO_FAST_RECORDS ? (int)std::min<size_t>(ctx->fastNodeCount, 0x7fffffff)
+               : option == RT_INFO_FAST_TRIANGLES ? (int)std::min<size_t>(ctx->fastTriCount, 0x7fffffff) : ctx->fastScene.stackDepth;
+        return RT_OK;
+    }
     case RT_INFO_STACK_DEPTH: *value = ctx->haveScene ? ctx->scene.stackDepth : 0; return RT_OK;
     case RT_INFO_RECORDS: *value = ctx->haveScene ? (int)std::min<size_t>(ctx->nodeCount, 0x7fffffff) : 0; return RT_OK;
     case RT_INFO_TRIANGLES: *value = ctx->haveScene ? (int)std::min<size_t>(ctx->triCount, 0x7fffffff) : 0; return RT_OK;
@@ -683,18 +913,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
     if ((rc = uploadArray(ctx, &ctx->dTris, rl.dTris.data(), rl.dTris.size() * sizeof(DevTri))) != RT_OK) return rc;
     if ((rc = uploadArray(ctx, &ctx->dNrms, nrms.data(), nrms.size() * sizeof(DevNrm))) != RT_OK) return rc;
     if ((rc = uploadArray(ctx, &ctx->dMaterials, b->materials.data, b->materials.count * sizeof(DevMaterial))) != RT_OK) return rc;
-    // order in which "any hit" rays visit the objects: leaf parents (a handful of triangles, no
-    // walk) before BVH parents; both groups keep their scene order
+    int32_t anyFirst = 0, anyLeafCount = 0;
     const int32_t P = (int32_t)rl.dObjects.size();
-    std::vector<int32_t> anyOrder, orderTables(2 * (size_t)P + 2, P);
-    for (int pass = 0; pass < 2; ++pass)
-        for (int32_t i = 0; i < P; ++i)
-            if ((rl.dObjects[i].root >= 0) == (pass == 1)) anyOrder.push_back(i);
-    for (int32_t p = 0; p < P; ++p) {
-        orderTables[p] = anyOrder[p];                                         // anyOrder
-        orderTables[P + 1 + anyOrder[p]] = p + 1 < P ? anyOrder[p + 1] : P;   // nextAny
-    }
-    if ((rc = uploadArray(ctx, &ctx->dAnyOrder, orderTables.data(), orderTables.size() * sizeof(int32_t))) != RT_OK) return rc;
+    const std::vector<int32_t> tables = orderTables(rl.dObjects, anyFirst, anyLeafCount);
+    if ((rc = uploadArray(ctx, &ctx->dAnyOrder, tables.data(), tables.size() * sizeof(int32_t))) != RT_OK) return rc;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die at return
 
     ctx->scene.objects = static_cast<const DevObject*>(ctx->dObjects);
@@ -704,15 +926,19 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
     ctx->scene.materials = static_cast<const DevMaterial*>(ctx->dMaterials);
     ctx->scene.anyOrder = static_cast<const int32_t*>(ctx->dAnyOrder);
     ctx->scene.nextAny = static_cast<const int32_t*>(ctx->dAnyOrder) + P + 1;
-    ctx->scene.anyFirst = P > 0 ? anyOrder[0] : 0;
-    ctx->scene.anyLeafCount = 0;
-    for (int i = 0; i < P; ++i) ctx->scene.anyLeafCount += rl.dObjects[i].root < 0 ? 1 : 0;
+    ctx->scene.anyFirst = anyFirst;
+    ctx->scene.anyLeafCount = anyLeafCount;
     ctx->scene.objectCount = (int32_t)rl.dObjects.size();
     ctx->scene.stackDepth = std::max(1, std::min(RT_MAX_STACK, rl.maxDepth));
+    ctx->scene.nearFirstBase = 0x7fffffff;
+    ctx->hStackDepth = ctx->scene.stackDepth;
     ctx->nodeCount = rl.dNodes.size();
     ctx->triCount = rl.dTris.size();
     ctx->sceneBytes = rl.dObjects.size() * sizeof(DevObject) + rl.dNodes.size() * sizeof(DevNode) + rl.dTris.size() * sizeof(DevTri) +
                       nrms.size() * sizeof(DevNrm) + b->materials.count * sizeof(DevMaterial);
+    ctx->hObjects = std::move(rl.dObjects);
+    ctx->hNodes = std::move(rl.dNodes);
+    ctx->hTris = std::move(rl.dTris);
     ctx->haveScene = true;
     return RT_OK;
 }

@@ -407,6 +407,9 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
         }
         int cur = root;
         if (!ok) continue;
+        // a root in the rebuilt part of the record array: this object's tree may be walked nearer
+        // child first (wave-uniform)
+        const bool nearFirst = !COUNT && root >= S.nearFirstBase;
 
         V3 lo = xform(ob->inv, org, 1.0f);
         V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
@@ -421,12 +424,20 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
             while ((unsigned)cur < (unsigned)RT_NONE) {
                 NodeVisit nv;
                 visit_node(S, cur, lo, linv, __any(parL), tMin, nv);
-                const int2 refs = nv.refs;
-                const float EF = nv.EF, ES = nv.ES;
+                int2 refs = nv.refs;
+                float EF = nv.EF, ES = nv.ES;
                 const bool okF = nv.okF, okS = nv.okS;
                 if (COUNT) cnt.nodeTests += (refs.x != RT_REF_ABSENT ? 1 : 0) + (refs.y != RT_REF_ABSENT ? 1 : 0);
                 bool goF = refs.x > RT_REF_LIVE_MIN && okF && (best.closest > EF);
                 bool canS = refs.y > RT_REF_LIVE_MIN && okS;
+                if (nearFirst) {
+                    // a child behind the closest hit is dropped at once; of two candidates the nearer goes first
+                    canS = canS && (best.closest > ES);
+                    if (goF && canS && ES < EF) {
+                        const int r = refs.x; refs.x = refs.y; refs.y = r;
+                        const float e = EF; EF = ES; ES = e;
+                    }
+                }
                 if (goF) {
                     if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(ES)); ++sp; }
                     cur = refs.x;
@@ -756,13 +767,21 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
         V3 linv = ld;
         bool parL = lean_inverse(ld, linv);
         int cur = root, sp = 0;
+        const bool nearFirst = root >= S.nearFirstBase;   // wave-uniform: a rebuilt tree, nearer child first
         for (;;) {
             while ((unsigned)cur < (unsigned)RT_NONE) {
                 NodeVisit nv;
                 visit_node(S, cur, lo, linv, __any(parL), tMin, nv);
-                const int2 refs = nv.refs;
+                int2 refs = nv.refs;
                 const bool goF = refs.x > RT_REF_LIVE_MIN && nv.okF && (bw.closest > nv.EF);
-                const bool canS = refs.y > RT_REF_LIVE_MIN && nv.okS;
+                bool canS = refs.y > RT_REF_LIVE_MIN && nv.okS;
+                if (nearFirst) {
+                    canS = canS && (bw.closest > nv.ES);
+                    if (goF && canS && nv.ES < nv.EF) {
+                        const int r = refs.x; refs.x = refs.y; refs.y = r;
+                        const float e = nv.EF; nv.EF = nv.ES; nv.ES = e;
+                    }
+                }
                 if (goF) {
                     if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(nv.ES)); ++sp; }
                     cur = refs.x;

@@ -1,0 +1,226 @@
+"""Near-first traversal (RT_OPT_TRAVERSAL = 1: trees rebuilt with a binned surface-area heuristic, nearer
+child first, tight world boxes) against the CPU oracle, which walks the reference's trees in the
+reference's order.
+
+GetHit's answer is the triangle with the smallest world-space distance whatever the visiting order, for
+every object that is not scaled below 1 (objects that are keep the reference's tree and order), so the
+only pixels that may differ are those where two triangles tie exactly or where a ray grazes the padded
+boxes. Bars, as stated for the renderer as a whole:
+  * 1 sample per pixel, linear accumulation value: >= 99.5 % of pixels within |d| <= 1e-4 + 1e-4*|ref| per
+    channel (measured: > 99.99 % are bit-identical); the outliers are counted and bounded;
+  * converged image (64 accumulated frames), gamma image: PSNR >= 45 dB against the oracle.
+Arithmetic stays strict binary32 (no FMA contraction): the traversal order is the only difference."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def to_pc(R, opc):
+    return R.PushConstants.from_buffer_copy(O.pc_bytes(opc).tobytes())
+
+
+def shares(a, ref, tol_abs=1e-4, tol_rel=1e-4):
+    """(share of pixels bit-identical, share within tolerance) over the rgb channels."""
+    same = np.all(bits(a[..., :3]) == bits(ref[..., :3]), axis=-1)
+    with np.errstate(invalid="ignore"):
+        ok = np.abs(a[..., :3] - ref[..., :3]) <= tol_abs + tol_rel * np.abs(ref[..., :3])
+    ok |= np.isnan(a[..., :3]) & np.isnan(ref[..., :3])
+    return float(same.mean()), float((np.all(ok, axis=-1) | same).mean())
+
+
+def psnr(out, ref):
+    a = np.clip(np.nan_to_num(out[..., :3]), 0, 1).astype(np.float64)
+    b = np.clip(np.nan_to_num(ref[..., :3]), 0, 1).astype(np.float64)
+    mse = np.mean((a - b) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+
+
+@pytest.fixture(scope="module")
+def R():
+    import raytracer_amd
+    return raytracer_amd
+
+
+def render(R, r, opc, frames, W, H, traversal, pipeline):
+    r.set_option(R.RT_OPT_PIPELINE, pipeline)
+    r.set_option(R.RT_OPT_TRAVERSAL, traversal)
+    if (r.width, r.height) != (W, H):
+        r.resize(W, H)
+    r.clear_accumulation()
+    opc["frame"] = frames[0]
+    if len(frames) == 1:
+        r.render_frame(to_pc(R, opc))
+    else:
+        r.render_frames(to_pc(R, opc), frames[0], frames[1] - frames[0], len(frames))
+    return r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW)
+
+
+def oracle(arrays, opc, frames, W, H, window=None):
+    acc = np.zeros((H, W, 4), np.float32)
+    res = None
+    for f in frames:
+        opc["frame"] = f
+        res = O.render(arrays, O.pc_bytes(opc), W, H, accum=acc, window=window)
+        acc = res["accum"]
+    return res["accum"], res["out"]
+
+
+@pytest.mark.parametrize("pipeline", [3, 0], ids=["two-samples", "lockstep"])
+def test_default_scene_1spp_and_converged(R, default_scene_arrays, pipeline):
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays)
+        assert r.get_option(R.RT_INFO_FAST_OBJECTS) == 2          # icosphere and dragon walk rebuilt trees
+        assert r.get_option(R.RT_INFO_FAST_STACK_DEPTH) <= 31
+        W, H = 640, 360
+        opc = scenes.make_pc(default_scene_arrays, W, H)
+        want_acc, want_out = oracle(default_scene_arrays, opc, [0], W, H)
+        acc, out = render(R, r, opc, [0], W, H, 1, pipeline)
+        same, ok = shares(acc, want_acc)
+        assert ok >= 0.995 and same >= 0.999, (same, ok)
+        assert np.all(acc[..., 3] == 0)
+        # two frames through rt_render_frames (pipeline 3: the two-samples-per-lane kernel)
+        want_acc, want_out = oracle(default_scene_arrays, opc, [0, 1], W, H)
+        acc, out = render(R, r, opc, [0, 1], W, H, 1, pipeline)
+        same, ok = shares(acc, want_acc)
+        assert ok >= 0.995 and same >= 0.999, (same, ok)
+        # converged: 64 frames
+        W, H = 256, 144
+        opc = scenes.make_pc(default_scene_arrays, W, H)
+        frames = list(range(64))
+        want_acc, want_out = oracle(default_scene_arrays, opc, frames, W, H)
+        acc, out = render(R, r, opc, frames, W, H, 1, pipeline)
+        assert psnr(out, want_out) >= 45.0
+        same, ok = shares(acc, want_acc)
+        assert ok >= 0.995, (same, ok)
+    finally:
+        r.close()
+
+
+def test_settings_and_partial_parent_count(R, default_scene_arrays):
+    """Samples per pixel, bounce count, defocus, sun settings: same bars. A dispatch with fewer parents
+    than were uploaded falls back to the reference order (bit-exact)."""
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays)
+        W, H = 200, 120
+        for fields in (dict(raysPerPixel=3), dict(maxBounces=7), dict(accumulateFrames=0, raysPerPixel=2),
+                       dict(sunDirection=(-0.3, -0.9, 0.2), sunIntensity=2.0)):
+            opc = scenes.make_pc(default_scene_arrays, W, H, **fields)
+            want_acc, want_out = oracle(default_scene_arrays, opc, [0, 1, 2], W, H)
+            acc, out = render(R, r, opc, [0, 1, 2], W, H, 1, 3)
+            same, ok = shares(acc, want_acc)
+            assert ok >= 0.995 and same >= 0.995, (fields, same, ok)
+            same, ok = shares(out, want_out)
+            assert ok >= 0.995, (fields, same, ok)
+        opc = scenes.make_pc(default_scene_arrays, W, H, cam_pos=(1.5, 3.0, 4.0), look=(-0.3, -0.25, -1.0), fov=55.0, focus=6.0, defocus=3.0)
+        want_acc, _ = oracle(default_scene_arrays, opc, [0, 1], W, H)
+        acc, _ = render(R, r, opc, [0, 1], W, H, 1, 3)
+        assert shares(acc, want_acc)[1] >= 0.995
+        opc = scenes.make_pc(default_scene_arrays, W, H)
+        opc["parentBVHCount"] = 5
+        want_acc, want_out = oracle(default_scene_arrays, opc, [0, 1], W, H)
+        acc, out = render(R, r, opc, [0, 1], W, H, 1, 3)
+        assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bits(out), bits(want_out))
+        # debug views and the counting build do not change with the option
+        for mode in (1, 2, 3, 4):
+            opc = scenes.make_pc(default_scene_arrays, W, H, renderMode=mode)
+            r.set_option(R.RT_OPT_TRAVERSAL, 1)
+            r.render_frame(to_pc(R, opc))
+            want = O.render(default_scene_arrays, O.pc_bytes(opc), W, H)["out"]
+            assert np.array_equal(bits(r.read_image(R.RT_IMAGE_DRAW)), bits(want)), mode
+        o = O.render(default_scene_arrays, O.pc_bytes(scenes.make_pc(default_scene_arrays, W, H)), W, H, counters=True)
+        st = r.frame_stats(to_pc(R, scenes.make_pc(default_scene_arrays, W, H)))
+        assert (st.rays, st.bvhNodeTests, st.triangleTests) == (int(o["rays"].sum()), int(o["node"].sum()), int(o["tri"].sum()))
+    finally:
+        r.close()
+
+
+def test_mixed_material_scene(R):
+    """Glass, mirror, fuzzy metal, emitter, open sky; objects scaled below 1 (teapot, icosphere, cottage,
+    dragon at 0.5) keep the reference's trees, the unit-scale cube and sphere walk rebuilt ones."""
+    materials, objects = scenes.mixed_recipe()
+    arrays = scenes.build_oracle(materials, objects).bindings()
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(arrays)
+        assert r.get_option(R.RT_INFO_FAST_OBJECTS) == 2
+        W, H = 320, 180
+        opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 2.5, 8.0), look=(0.0, -0.15, -1.0), fov=60.0, maxBounces=5)
+        want_acc, want_out = oracle(arrays, opc, [0, 1], W, H)
+        for pipeline in (3, 0):
+            acc, out = render(R, r, opc, [0, 1], W, H, 1, pipeline)
+            same, ok = shares(acc, want_acc)
+            assert ok >= 0.995 and same >= 0.99, (pipeline, same, ok)
+        frames = list(range(64))
+        W, H = 192, 108
+        opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 2.5, 8.0), look=(0.0, -0.15, -1.0), fov=60.0, maxBounces=5)
+        want_acc, want_out = oracle(arrays, opc, frames, W, H)
+        acc, out = render(R, r, opc, frames, W, H, 1, 3)
+        assert psnr(out, want_out) >= 45.0
+    finally:
+        r.close()
+
+
+def test_only_shrunk_objects_is_bit_exact(R):
+    """A scene in which every BVH object is scaled below 1: nothing is rebuilt, only the world boxes are
+    tightened, and the image is the reference-order image bit for bit."""
+    materials = [scenes.mat((0.5, 0.5, 0.5)), scenes.mat((0.8, 0.3, 0.2)), scenes.mat((1, 1, 1), smoothness=1.0)]
+    objects = [("flat_quad.obj", (0, 0, 0), (0, 0, 0), (12, 12, 12), 0),
+               ("teapot.obj", (0.0, 0.0, -2.5), (0, -40, 0), (0.6, 0.6, 0.6), 1),
+               ("dragon_lowres.obj", (3.0, 1.2, -3.0), (0, 120, 0), (0.5, 0.7, 0.5), 2)]
+    arrays = scenes.build_oracle(materials, objects).bindings()
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(arrays)
+        assert r.get_option(R.RT_INFO_FAST_OBJECTS) == 0
+        W, H = 256, 144
+        opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 2.5, 8.0), look=(0.0, -0.15, -1.0), fov=60.0)
+        want_acc, want_out = oracle(arrays, opc, [0, 1], W, H)
+        acc, out = render(R, r, opc, [0, 1], W, H, 1, 3)
+        same, ok = shares(acc, want_acc)
+        assert same >= 0.9999, same        # tight world boxes only: a grazing ray at most
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("name", ["heightfield", "blob_grid"])
+def test_generated_configs_full_size(R, name, tmp_path_factory):
+    """The 100 352-triangle height field and the 999 424-triangle mixed-material scene at 1920x1080:
+    the whole image against the reference-order kernel's (itself bit-exact with the oracle), oracle
+    windows, and the rebuilt trees' depth."""
+    from raytracer_amd import scenefile as SF
+    tmp = str(tmp_path_factory.mktemp("gen_" + name))
+    desc = SF.config_heightfield(tmp) if name == "heightfield" else SF.config_blob_grid(tmp)
+    scene, cam, pc = SF.build_scene(desc, tmp)
+    arrays = scene.buffers().to_arrays()
+    W, H = desc["width"], desc["height"]
+    opc = np.frombuffer(bytes(pc.as_bytes()), dtype=O.PC_DTYPE).copy()
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(scene.buffers())
+        assert r.get_option(R.RT_INFO_FAST_OBJECTS) == (1 if name == "heightfield" else 64)
+        assert r.get_option(R.RT_INFO_FAST_STACK_DEPTH) <= 31
+        ref_acc, ref_out = render(R, r, opc, [0, 1], W, H, 0, 3)
+        acc, out = render(R, r, opc, [0, 1], W, H, 1, 3)
+        same, ok = shares(acc, ref_acc)
+        assert ok >= 0.995 and same >= 0.999, (same, ok)
+        acc0, out0 = render(R, r, opc, [0, 1], W, H, 1, 0)
+        assert shares(acc0, ref_acc)[1] >= 0.995
+        for win in ([(900, 520, 1028, 568), (300, 700, 396, 748)] if name == "heightfield" else [(900, 500, 996, 548), (600, 640, 664, 688)]):
+            x0, y0, x1, y1 = win
+            wa, wo = oracle(arrays, opc, [0, 1], W, H, window=win)
+            same, ok = shares(acc[y0:y1, x0:x1], wa[y0:y1, x0:x1])
+            assert ok >= 0.995, (win, same, ok)
+    finally:
+        r.close()
