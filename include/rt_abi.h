@@ -68,8 +68,9 @@ enum {
     RT_OPT_PIPELINE    = 2,
     /* Tile partition for multi-GPU tile split: this context renders only the
      * tiles t with t % RT_OPT_TILE_WORLD == RT_OPT_TILE_RANK (tiles are
-     * RT_OPT_TILE_SIZE x RT_OPT_TILE_SIZE pixels, numbered row-major). Pixels of
-     * other tiles are left untouched. Defaults: rank 0, world 1, size 64. */
+     * RT_OPT_TILE_SIZE x RT_OPT_TILE_SIZE pixels, numbered along a serpentine path:
+     * row 0 left to right, row 1 right to left, ...). Pixels of other tiles are left
+     * untouched. Defaults: rank 0, world 1, size 64. */
     RT_OPT_TILE_RANK   = 3,
     RT_OPT_TILE_WORLD  = 4,
     RT_OPT_TILE_SIZE   = 5,
@@ -178,6 +179,31 @@ int rt_write_accum(rt_ctx* ctx, const float* src_rgba, size_t bytes);
  * Pathtrace (raytrace.comp:794-801) applied to an accumulation image that was
  * merged from several GPUs. */
 int rt_resolve(rt_ctx* ctx, int total_frames);
+
+/* ---- several GPUs: one process per GPU, RCCL over xGMI ---------------------------------------
+ * The reference renders on one GPU; these calls have no counterpart in it. They spread its progressive
+ * accumulation (ProduceRender, HardwareRenderer.cpp:1030-1061) over the GPUs of a node:
+ *   sample split: rank r of W renders frames r, r+W, ... (rt_render_frames(ctx, pc, r, W, n)) into its own
+ *     accumulation image, rt_merge_accum sums the images of all ranks (one all-reduce of width*height*4
+ *     floats), rt_resolve(ctx, n*W) produces the draw image;
+ *   tile split: rank r renders all frames of the tiles it owns (RT_OPT_TILE_RANK = r, RT_OPT_TILE_WORLD = W),
+ *     rt_gather_tiles hands every rank's tiles of both images to every other rank (one all-gather in which
+ *     each rank sends its own 1/W of the pixels): bit-identical to a single-GPU render.
+ * Rank 0 calls rt_comm_unique_id and passes the 128 bytes to the other ranks by any channel; every rank
+ * calls rt_comm_init (collective, like ncclCommInitRank). librccl is loaded at that moment. The merges are
+ * enqueued on the context's stream behind the render kernels; they do not synchronise the host. */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(unsigned char id[RT_COMM_ID_BYTES]);
+int rt_comm_init(rt_ctx* ctx, const unsigned char id[RT_COMM_ID_BYTES], int rank, int world);
+int rt_comm_destroy(rt_ctx* ctx);
+/* rank and size of the context's communicator (world = 0: none). */
+int rt_comm_info(rt_ctx* ctx, int* rank, int* world);
+int rt_merge_accum(rt_ctx* ctx);
+int rt_gather_tiles(rt_ctx* ctx);
+/* The same two merges among n contexts of ONE process (on one device or several) by device copies, no
+ * communicator needed: context i is rank i of n. Synchronise. rt_merge_accum_local adds in rank order. */
+int rt_merge_accum_local(rt_ctx** ctxs, int n);
+int rt_gather_tiles_local(rt_ctx** ctxs, int n);
 
 /* Runs the same dispatch as rt_render_frame on a counting build of the kernel
  * that writes no image and returns the work counters summed over all pixels

@@ -135,6 +135,9 @@ def load_library():
         "rt_sync": (ci, [vp]), "rt_read_image": (ci, [vp, ci, vp, C.c_size_t]), "rt_write_accum": (ci, [vp, vp, C.c_size_t]),
         "rt_resolve": (ci, [vp, ci]), "rt_frame_stats_compute": (ci, [vp, P(PushConstants), P(FrameStats)]),
         "rt_frame_stats_noalloc": (ci, [vp, P(PushConstants), vp]),
+        "rt_comm_unique_id": (ci, [vp]), "rt_comm_init": (ci, [vp, vp, ci, ci]), "rt_comm_destroy": (ci, [vp]),
+        "rt_comm_info": (ci, [vp, P(ci), P(ci)]), "rt_merge_accum": (ci, [vp]), "rt_gather_tiles": (ci, [vp]),
+        "rt_merge_accum_local": (ci, [P(vp), ci]), "rt_gather_tiles_local": (ci, [P(vp), ci]),
         "rt_schedule_stats": (ci, [vp, P(PushConstants), P(C.c_uint64)]),
         "rt_last_render_ms": (ci, [vp, P(cf), P(cf)]), "rt_image_size": (ci, [vp, P(ci), P(ci)]),
         "rt_last_error": (C.c_char_p, [vp]), "rt_version": (C.c_char_p, []),
@@ -174,7 +177,8 @@ EXPORTED_SYMBOLS = [
     "rt_scene_load_model", "rt_scene_add_object", "rt_scene_set_object", "rt_scene_set_material", "rt_scene_buffer_data",
     "rt_scene_get_buffers", "rt_scene_init_default", "rt_scene_model_info", "rt_rgba32f_to_rgba8", "rt_write_png_rgba8",
     "rt_save_png", "rt_produce_render", "rt_math_apply", "rt_scene_object_count", "rt_scene_material_count",
-    "rt_scene_get_object", "rt_scene_get_material", "rt_frame_stats_noalloc"]
+    "rt_scene_get_object", "rt_scene_get_material", "rt_frame_stats_noalloc", "rt_comm_unique_id", "rt_comm_init",
+    "rt_comm_destroy", "rt_comm_info", "rt_merge_accum", "rt_gather_tiles", "rt_merge_accum_local", "rt_gather_tiles_local"]
 
 
 def _f3(v):
@@ -217,6 +221,33 @@ def rgba32f_to_rgba8(img):
     out = np.zeros(img.shape, np.uint8)
     load_library().rt_rgba32f_to_rgba8(img.ctypes.data, out.ctypes.data, img.size // 4)
     return out
+
+
+def comm_unique_id():
+    """rt_comm_unique_id: 128 bytes that rank 0 creates and every rank passes to Renderer.comm_init."""
+    buf = (C.c_ubyte * 128)()
+    rc = load_library().rt_comm_unique_id(buf)
+    if rc != 0:
+        raise RtError(rc, load_library().rt_last_error(None).decode())
+    return bytes(buf)
+
+
+def _ctx_array(renderers):
+    return (C.c_void_p * len(renderers))(*[r.h for r in renderers])
+
+
+def merge_accum_local(renderers):
+    """rt_merge_accum_local: sum the accumulation images of several contexts of this process."""
+    rc = load_library().rt_merge_accum_local(_ctx_array(renderers), len(renderers))
+    if rc != 0:
+        raise RtError(rc, load_library().rt_last_error(None).decode())
+
+
+def gather_tiles_local(renderers):
+    """rt_gather_tiles_local: exchange the owned tiles among several contexts of this process."""
+    rc = load_library().rt_gather_tiles_local(_ctx_array(renderers), len(renderers))
+    if rc != 0:
+        raise RtError(rc, load_library().rt_last_error(None).decode())
 
 
 def write_png_rgba8(path, rgba8):
@@ -385,6 +416,26 @@ class Renderer:
         """rt_frame_stats_noalloc: enqueue only; out_ptr is the address of 32 bytes the GPU can write
         (four uint64: rays, bvhNodeTests, triangleTests, samples), valid after sync()."""
         self._check(self.lib.rt_frame_stats_noalloc(self.h, C.byref(pc), out_ptr))
+
+    # ---- several GPUs (one process per GPU): RCCL communicator owned by the library ----
+    def comm_init(self, unique_id, rank, world):
+        """rt_comm_init; unique_id: the 128 bytes rank 0 got from comm_unique_id()."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self.lib.rt_comm_init(self.h, buf, rank, world))
+
+    def comm_destroy(self):
+        self._check(self.lib.rt_comm_destroy(self.h))
+
+    def comm_info(self):
+        a, b = C.c_int(), C.c_int()
+        self._check(self.lib.rt_comm_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def merge_accum(self):
+        self._check(self.lib.rt_merge_accum(self.h))
+
+    def gather_tiles(self):
+        self._check(self.lib.rt_gather_tiles(self.h))
 
     def schedule_stats(self, pc):
         out = (C.c_uint64 * 16)()

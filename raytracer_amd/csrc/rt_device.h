@@ -88,12 +88,28 @@ struct DevScene {
     int32_t            nearFirstBase;
 };
 
+#if defined(__HIPCC__)
+#define RT_HOST_DEVICE __host__ __device__
+#else
+#define RT_HOST_DEVICE
+#endif
+
+/* Tiles of the partition are numbered along a serpentine path: row 0 left to right, row 1 right to
+ * left, and so on, so that consecutive numbers are neighbouring tiles and dealing them out round-robin
+ * gives every rank a sample of every part of the image. */
+static inline RT_HOST_DEVICE void rt_tile_of_position(int p, int tilesX, int* tx, int* ty)
+{
+    const int row = p / tilesX, col = p - row * tilesX;
+    *ty = row;
+    *tx = (row & 1) ? tilesX - 1 - col : col;
+}
+
 struct DevLaunch {
     int32_t width, height;
     int32_t tileSize;      /* partition tile edge in pixels, multiple of 8 */
     int32_t tilesX, tilesY;
     int32_t tileRank, tileWorld;
-    int32_t ownedTiles;    /* number of tiles t with t % tileWorld == tileRank */
+    int32_t ownedTiles;    /* number of tiles t (serpentine numbers) with t % tileWorld == tileRank */
     /* round selection of the wave-scheduled kernel: the kind with the largest (waiting lanes -
      * bias) runs; a BVH round ends when fewer than max(quorumMin, started/quorumDiv) lanes walk */
     int32_t biasObject, biasTrav, biasShade, quorumMin, quorumDiv;

@@ -24,6 +24,7 @@
 
 #include "../../include/rt_abi.h"
 #include "rt_device.h"
+#include "rt_ctx.h"
 
 void rt_mat4_inverse(const float in[16], float out[16]);   // rt_scene.cpp
 int32_t rt_build_sah(const DevTri* src, size_t count, int maxLeaf, std::vector<DevNode>& nodes, std::vector<DevTri>& tris,
@@ -58,94 +59,25 @@ long long rt_noalloc_max_waves(void);
 hipError_t rt_noalloc_sum(const void* partials, int n, void* out, hipStream_t stream);
 }
 
-struct rt_ctx {
-    int device = 0;
-    hipStream_t ownStream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t evStart = nullptr, evStop = nullptr;
-    bool timed = false;
-    int lastFrames = 0;
 
-    // scene in HBM
-    DevScene scene{};
-    void* dObjects = nullptr;
-    void* dNodes = nullptr;
-    void* dTris = nullptr;
-    void* dNrms = nullptr;
-    void* dMaterials = nullptr;
-    void* dAnyOrder = nullptr;
-    bool haveScene = false;
-    size_t sceneBytes = 0;
-    size_t nodeCount = 0, triCount = 0;
+thread_local std::string g_rtError;
 
-    // host copies of the re-laid-out scene (the caller's arrays may be gone after rt_upload_scene) and the
-    // near-first scene built from them on first use (RT_OPT_TRAVERSAL = 1): its own object records
-    // (tight world boxes, roots in the rebuilt trees), and record / triangle arrays that hold the
-    // rebuilt trees (behind a copy of the reference-order records when some object has to keep those)
-    std::vector<DevObject> hObjects;
-    std::vector<DevNode> hNodes;
-    std::vector<DevTri> hTris;
-    int hStackDepth = 0;
-    DevScene fastScene{};
-    void* dFastObjects = nullptr;
-    void* dFastNodes = nullptr;
-    void* dFastTris = nullptr;
-    void* dFastAnyOrder = nullptr;
-    bool haveFast = false;
-    int fastObjects = 0;          // objects that walk a rebuilt tree
-    size_t fastNodeCount = 0, fastTriCount = 0;
-    int optTraversal = 0, sahMaxLeaf = 4;
-
-    // images
-    int width = 0, height = 0;
-    void* ownDraw = nullptr;
-    void* ownAccum = nullptr;
-    void* draw = nullptr;
-    void* accum = nullptr;
-
-    DevCounters* dCounters = nullptr;
-    unsigned long long* dQueue = nullptr;   // pixel counter of the wave-scheduled kernel
-    int computeUnits = 0;
-    int wavesPerCU = 12;
-    int policy[5] = { 0, 0, 0, 4, 8 };   // biasObject, biasTrav, biasShade, quorumMin, quorumDiv
-
-    // wavefront pipeline: the image is dealt out to wfParts independent partitions (tile split inside
-    // one GPU), each with its own job buffers and stream, so that the thin end of one partition's
-    // kernels overlaps with the bulk of another's
-    static const int kMaxParts = 8;
-    DevWavefront wf[kMaxParts]{};
-    void* wfMem[kMaxParts] = {};
-    hipStream_t wfStream[kMaxParts] = {};
-    hipEvent_t wfFork = nullptr, wfJoin[kMaxParts] = {};
-    size_t wfKey[6] = {};
-    int wfRounds = 5, wfRefill = 16, wfWalkWaves = 12, wfParts = 1;
-    int framesPerLaunch = 8;
-
-    int optFast = 0, optPipeline = 3, tileRank = 0, tileWorld = 1, tileSize = 64;
-    std::string error;
-};
-
-namespace {
-
-thread_local std::string g_error;
-
-int fail(rt_ctx* ctx, int code, const std::string& msg)
+int rt_fail(rt_ctx* ctx, int code, const std::string& msg)
 {
     if (ctx) ctx->error = msg;
-    g_error = msg;
+    g_rtError = msg;
     return code;
 }
 
-int failHip(rt_ctx* ctx, hipError_t e, const char* what)
+int rt_fail_hip(rt_ctx* ctx, hipError_t e, const char* what)
 {
-    return fail(ctx, RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return rt_fail(ctx, RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
-#define RT_HIP(ctx, call)                                         \
-    do {                                                          \
-        hipError_t e_ = (call);                                   \
-        if (e_ != hipSuccess) return failHip(ctx, e_, #call);     \
-    } while (0)
+const char* rt_global_error() { return g_rtError.c_str(); }
+
+namespace {
+
 
 void freeFastScene(rt_ctx* c)
 {
@@ -494,7 +426,7 @@ int ensureFastScene(rt_ctx* ctx)
         }
         if (o.bmin[0] > o.bmax[0] || o.bmin[1] > o.bmax[1] || o.bmin[2] > o.bmax[2]) o.root = RT_REF_DEAD;
     }
-    if (depth > RT_MAX_STACK) return fail(ctx, RT_ERR_UNSUPPORTED, "rebuilt tree deeper than the traversal stack");
+    if (depth > RT_MAX_STACK) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rebuilt tree deeper than the traversal stack");
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -546,15 +478,15 @@ DevLaunch makeLaunch(const rt_ctx* c)
 
 int checkRenderable(rt_ctx* ctx, const rt_push_constants* pc)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
-    if (!pc) return fail(ctx, RT_ERR_INVALID_ARG, "null push constants");
-    if (!ctx->haveScene) return fail(ctx, RT_ERR_NO_SCENE, "no scene uploaded (call rt_upload_scene first)");
-    if (!ctx->draw || !ctx->accum) return fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
+    if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!pc) return rt_fail(ctx, RT_ERR_INVALID_ARG, "null push constants");
+    if (!ctx->haveScene) return rt_fail(ctx, RT_ERR_NO_SCENE, "no scene uploaded (call rt_upload_scene first)");
+    if (!ctx->draw || !ctx->accum) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
     if (pc->parentBVHCount < 0 || pc->parentBVHCount > ctx->scene.objectCount)
-        return fail(ctx, RT_ERR_INVALID_ARG, "parentBVHCount " + std::to_string(pc->parentBVHCount) + " exceeds the " +
+        return rt_fail(ctx, RT_ERR_INVALID_ARG, "parentBVHCount " + std::to_string(pc->parentBVHCount) + " exceeds the " +
                                                  std::to_string(ctx->scene.objectCount) + " uploaded parent nodes");
     if (pc->renderMode == 0 || pc->renderMode == 3 || pc->renderMode == 4) {
-        if (pc->raysPerPixel < 0) return fail(ctx, RT_ERR_INVALID_ARG, "raysPerPixel is negative");
+        if (pc->raysPerPixel < 0) return rt_fail(ctx, RT_ERR_INVALID_ARG, "raysPerPixel is negative");
     }
     return RT_OK;
 }
@@ -586,7 +518,7 @@ int ensureWavefront(rt_ctx* ctx, const DevLaunch& L, int parts)
         // block of 256 entries per wave of the path kernel's grid
         const size_t pixels = (size_t)P.ownedTiles * (size_t)L.tileSize * (size_t)L.tileSize;
         const size_t listCap = ((pixels + cus * (size_t)ctx->wavesPerCU * 256 + 63) / 64) * 64 + 64;
-        if (listCap > 0x7fffffffULL) return fail(ctx, RT_ERR_UNSUPPORTED, "image too large for the wavefront pipeline");
+        if (listCap > 0x7fffffffULL) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "image too large for the wavefront pipeline");
         const size_t ctlBytes = 4096;
         static_assert((RT_WF_MAX_ROUNDS + 2) * RT_WF_WORDS_PER_ROUND * sizeof(uint32_t) <= 4096, "control block");
         const size_t jobBytes = (size_t)RT_WF_JOB_ARRAYS * listCap * 16;
@@ -632,7 +564,7 @@ int launchWavefront(rt_ctx* ctx, const rt_push_constants& pc, const DevLaunch& L
         W.refillMin = std::max(1, std::min(64, ctx->wfRefill));
         RT_HIP(ctx, hipMemsetAsync(W.counts, 0, 4096, stream));
         const long long tileWaves = (long long)P.ownedTiles * (P.tileSize / 8) * (P.tileSize / 8);
-        if (tileWaves > 0x7fffffffLL) return fail(ctx, RT_ERR_UNSUPPORTED, "too many tiles");
+        if (tileWaves > 0x7fffffffLL) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "too many tiles");
         hipError_t e = path(&ctx->scene, &pc, &P, &W, ctx->accum, ctx->draw, cnt, countBuild ? 1 : 0, statsOnly ? 1 : 0, 0,
                             rounds == 0 ? 1 : 0, (int)std::min<long long>(tileWaves, resident), stream);
         for (int r = 0; r < rounds && e == hipSuccess; ++r) {
@@ -641,7 +573,7 @@ int launchWavefront(rt_ctx* ctx, const rt_push_constants& pc, const DevLaunch& L
             e = path(&ctx->scene, &pc, &P, &W, ctx->accum, ctx->draw, cnt, countBuild ? 1 : 0, statsOnly ? 1 : 0, r + 1,
                      r + 1 == rounds ? 1 : 0, resident, stream);
         }
-        if (e != hipSuccess) return failHip(ctx, e, "kernel launch");
+        if (e != hipSuccess) return rt_fail_hip(ctx, e, "kernel launch");
         if (parts > 1 && join) {
             RT_HIP(ctx, hipEventRecord(ctx->wfJoin[k], stream));
             RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->wfJoin[k], 0));
@@ -687,7 +619,7 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
         e = fn(scene, &pc, &L, ctx->accum, ctx->draw, statsOnly ? ctx->dCounters : nullptr, countBuild ? 1 : 0,
                statsOnly ? 1 : 0, ctx->stream);
     }
-    if (e != hipSuccess) return failHip(ctx, e, "kernel launch");
+    if (e != hipSuccess) return rt_fail_hip(ctx, e, "kernel launch");
     return RT_OK;
 }
 
@@ -697,18 +629,18 @@ extern "C" {
 
 const char* rt_version(void) { return "rt_amd 0.1 (gfx950)"; }
 
-const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->error.c_str() : rt_global_error(); }
 
 int rt_create(int device_id, rt_ctx** out_ctx)
 {
-    if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: null out pointer");
+    if (!out_ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: null out pointer");
     *out_ctx = nullptr;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device available: this library has no CPU path");
-    if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_INVALID_ARG, "device ordinal out of range");
+    if (e != hipSuccess || n <= 0) return rt_fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device available: this library has no CPU path");
+    if (device_id < 0 || device_id >= n) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "device ordinal out of range");
     rt_ctx* c = new (std::nothrow) rt_ctx();
-    if (!c) return fail(nullptr, RT_ERR_HIP, "out of host memory");
+    if (!c) return rt_fail(nullptr, RT_ERR_HIP, "out of host memory");
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
@@ -716,7 +648,7 @@ int rt_create(int device_id, rt_ctx** out_ctx)
         (e = hipMalloc((void**)&c->dQueue, 256)) != hipSuccess ||
         (e = hipDeviceGetAttribute(&c->computeUnits, hipDeviceAttributeMultiprocessorCount, device_id)) != hipSuccess ||
         (e = rt_noalloc_setup(device_id)) != hipSuccess) {
-        int rc = failHip(nullptr, e, "rt_create");
+        int rc = rt_fail_hip(nullptr, e, "rt_create");
         rt_destroy(c);
         return rc;
     }
@@ -730,6 +662,7 @@ void rt_destroy(rt_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)rt_comm_destroy(c);
     freeScene(c);
     freeImages(c);
     for (int k = 0; k < rt_ctx::kMaxParts; ++k) {
@@ -748,7 +681,7 @@ void rt_destroy(rt_ctx* c)
 
 int rt_set_stream(rt_ctx* ctx, void* hip_stream)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->ownStream;
@@ -758,44 +691,44 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream)
 
 int rt_set_option(rt_ctx* ctx, int option, int value)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     switch (option) {
     case RT_OPT_FAST_MATH: ctx->optFast = value ? 1 : 0; return RT_OK;
     case RT_OPT_PIPELINE:
-        if (value < 0 || value > 3) return fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step), 1 (wave-scheduled), 2 (wavefront) or 3 (lock-step, two samples per lane)");
+        if (value < 0 || value > 3) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step), 1 (wave-scheduled), 2 (wavefront) or 3 (lock-step, two samples per lane)");
         ctx->optPipeline = value;
         return RT_OK;
     case RT_OPT_WAVES_PER_CU:
-        if (value < 1 || value > 32) return fail(ctx, RT_ERR_INVALID_ARG, "waves per CU must be in [1,32]");
+        if (value < 1 || value > 32) return rt_fail(ctx, RT_ERR_INVALID_ARG, "waves per CU must be in [1,32]");
         ctx->wavesPerCU = value;
         return RT_OK;
     case RT_OPT_SCHED_BIAS_OBJECT: case RT_OPT_SCHED_BIAS_TRAV: case RT_OPT_SCHED_BIAS_SHADE:
     case RT_OPT_SCHED_QUORUM_MIN: case RT_OPT_SCHED_QUORUM_DIV:
-        if (value < -64 || value > 64) return fail(ctx, RT_ERR_INVALID_ARG, "scheduling parameter out of range");
+        if (value < -64 || value > 64) return rt_fail(ctx, RT_ERR_INVALID_ARG, "scheduling parameter out of range");
         ctx->policy[option - RT_OPT_SCHED_BIAS_OBJECT] = value;
         return RT_OK;
     case RT_OPT_WF_ROUNDS:
-        if (value < 0 || value > RT_WF_MAX_ROUNDS) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront rounds must be in [0,30]");
+        if (value < 0 || value > RT_WF_MAX_ROUNDS) return rt_fail(ctx, RT_ERR_INVALID_ARG, "wavefront rounds must be in [0,30]");
         ctx->wfRounds = value;
         return RT_OK;
     case RT_OPT_WF_WALK_WAVES:
-        if (value < 1 || value > 32) return fail(ctx, RT_ERR_INVALID_ARG, "walk waves per CU must be in [1,32]");
+        if (value < 1 || value > 32) return rt_fail(ctx, RT_ERR_INVALID_ARG, "walk waves per CU must be in [1,32]");
         ctx->wfWalkWaves = value;
         return RT_OK;
     case RT_OPT_WF_PARTS:
-        if (value < 1 || value > rt_ctx::kMaxParts) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront partitions must be in [1,8]");
+        if (value < 1 || value > rt_ctx::kMaxParts) return rt_fail(ctx, RT_ERR_INVALID_ARG, "wavefront partitions must be in [1,8]");
         ctx->wfParts = value;
         return RT_OK;
     case RT_OPT_FRAMES_PER_LAUNCH:
-        if (value < 1 || value > 4096) return fail(ctx, RT_ERR_INVALID_ARG, "frames per launch must be in [1,4096]");
+        if (value < 1 || value > 4096) return rt_fail(ctx, RT_ERR_INVALID_ARG, "frames per launch must be in [1,4096]");
         ctx->framesPerLaunch = value;
         return RT_OK;
     case RT_OPT_TRAVERSAL:
-        if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID_ARG, "traversal must be 0 (reference order) or 1 (near-first on rebuilt trees)");
+        if (value != 0 && value != 1) return rt_fail(ctx, RT_ERR_INVALID_ARG, "traversal must be 0 (reference order) or 1 (near-first on rebuilt trees)");
         ctx->optTraversal = value;
         return RT_OK;
     case RT_OPT_SAH_MAX_LEAF:
-        if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARG, "triangles per rebuilt leaf must be in [1,64]");
+        if (value < 1 || value > 64) return rt_fail(ctx, RT_ERR_INVALID_ARG, "triangles per rebuilt leaf must be in [1,64]");
         if (value != ctx->sahMaxLeaf) {
             RT_HIP(ctx, hipSetDevice(ctx->device));
             RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -804,28 +737,28 @@ int rt_set_option(rt_ctx* ctx, int option, int value)
         ctx->sahMaxLeaf = value;
         return RT_OK;
     case RT_OPT_WF_REFILL:
-        if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID_ARG, "wavefront refill threshold must be in [1,64]");
+        if (value < 1 || value > 64) return rt_fail(ctx, RT_ERR_INVALID_ARG, "wavefront refill threshold must be in [1,64]");
         ctx->wfRefill = value;
         return RT_OK;
     case RT_OPT_TILE_RANK:
-        if (value < 0) return fail(ctx, RT_ERR_INVALID_ARG, "tile rank must be >= 0");
+        if (value < 0) return rt_fail(ctx, RT_ERR_INVALID_ARG, "tile rank must be >= 0");
         ctx->tileRank = value;
         return RT_OK;
     case RT_OPT_TILE_WORLD:
-        if (value < 1) return fail(ctx, RT_ERR_INVALID_ARG, "tile world must be >= 1");
+        if (value < 1) return rt_fail(ctx, RT_ERR_INVALID_ARG, "tile world must be >= 1");
         ctx->tileWorld = value;
         return RT_OK;
     case RT_OPT_TILE_SIZE:
-        if (value < 8 || value > 1024 || (value & 7)) return fail(ctx, RT_ERR_INVALID_ARG, "tile size must be a multiple of 8 in [8,1024]");
+        if (value < 8 || value > 1024 || (value & 7)) return rt_fail(ctx, RT_ERR_INVALID_ARG, "tile size must be a multiple of 8 in [8,1024]");
         ctx->tileSize = value;
         return RT_OK;
-    default: return fail(ctx, RT_ERR_INVALID_ARG, "unknown option");
+    default: return rt_fail(ctx, RT_ERR_INVALID_ARG, "unknown option");
     }
 }
 
 int rt_get_option(rt_ctx* ctx, int option, int* value)
 {
-    if (!ctx || !value) return fail(ctx, RT_ERR_INVALID_ARG, "null argument");
+    if (!ctx || !value) return rt_fail(ctx, RT_ERR_INVALID_ARG, "null argument");
     switch (option) {
     case RT_OPT_FAST_MATH: *value = ctx->optFast; return RT_OK;
     case RT_OPT_PIPELINE: *value = ctx->optPipeline; return RT_OK;
@@ -852,27 +785,27 @@ int rt_get_option(rt_ctx* ctx, int option, int* value)
     case RT_OPT_TILE_RANK: *value = ctx->tileRank; return RT_OK;
     case RT_OPT_TILE_WORLD: *value = ctx->tileWorld; return RT_OK;
     case RT_OPT_TILE_SIZE: *value = ctx->tileSize; return RT_OK;
-    default: return fail(ctx, RT_ERR_INVALID_ARG, "unknown option");
+    default: return rt_fail(ctx, RT_ERR_INVALID_ARG, "unknown option");
     }
 }
 
 int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
 {
-    if (!ctx || !b) return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: null argument");
+    if (!ctx || !b) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: null argument");
     // shape checks that must hold before any array is indexed
     const size_t T = b->triangleV0s.count;
     for (const rt_buffer_view* v : { &b->triangleV1s, &b->triangleV2s, &b->triangleN0s, &b->triangleN1s, &b->triangleN2s })
-        if (v->count != T) return fail(ctx, RT_ERR_SCENE_INVALID, "the six triangle arrays must have the same length");
+        if (v->count != T) return rt_fail(ctx, RT_ERR_SCENE_INVALID, "the six triangle arrays must have the same length");
     const size_t N = b->aabbMins.count;
     for (const rt_buffer_view* v : { &b->aabbMaxs, &b->bvhNodeLeftChildren, &b->bvhNodeRightChildren,
                                      &b->bvhNodeTriangleStartIndices, &b->bvhNodeTriangleCounts })
-        if (v->count != N) return fail(ctx, RT_ERR_SCENE_INVALID, "the six BVH node arrays must have the same length");
+        if (v->count != N) return rt_fail(ctx, RT_ERR_SCENE_INVALID, "the six BVH node arrays must have the same length");
     for (const rt_buffer_view* v : { &b->parentBVH, &b->objects, &b->materials, &b->triangleV0s, &b->triangleV1s, &b->triangleV2s,
                                      &b->triangleN0s, &b->triangleN1s, &b->triangleN2s, &b->aabbMins, &b->aabbMaxs,
                                      &b->bvhNodeLeftChildren, &b->bvhNodeRightChildren, &b->bvhNodeTriangleStartIndices,
                                      &b->bvhNodeTriangleCounts })
-        if (v->count != 0 && v->data == nullptr) return fail(ctx, RT_ERR_INVALID_ARG, "a non-empty buffer view has a null pointer");
-    if (T >= 0x7ffffff0u || N >= 0x7ffffff0u) return fail(ctx, RT_ERR_SCENE_INVALID, "scene too large for 32-bit indices");
+        if (v->count != 0 && v->data == nullptr) return rt_fail(ctx, RT_ERR_INVALID_ARG, "a non-empty buffer view has a null pointer");
+    if (T >= 0x7ffffff0u || N >= 0x7ffffff0u) return rt_fail(ctx, RT_ERR_SCENE_INVALID, "scene too large for 32-bit indices");
 
     {
         auto finite = [](const void* p, size_t vec4s) {
@@ -883,15 +816,15 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
             return true;
         };
         if (!finite(b->aabbMins.data, N) || !finite(b->aabbMaxs.data, N))
-            return fail(ctx, RT_ERR_SCENE_INVALID, "a BVH node box has a non-finite coordinate");
+            return rt_fail(ctx, RT_ERR_SCENE_INVALID, "a BVH node box has a non-finite coordinate");
         const rt_parent_bvh_node* pp = static_cast<const rt_parent_bvh_node*>(b->parentBVH.data);
         for (size_t i = 0; i < b->parentBVH.count; ++i)
             for (int k = 0; k < 3; ++k)
                 if (!std::isfinite(pp[i].node.aabb.min[k]) || !std::isfinite(pp[i].node.aabb.max[k]))
-                    return fail(ctx, RT_ERR_SCENE_INVALID, "a parent box has a non-finite coordinate");
+                    return rt_fail(ctx, RT_ERR_SCENE_INVALID, "a parent box has a non-finite coordinate");
     }
     Relayout rl(*b);
-    if (!rl.run()) return fail(ctx, RT_ERR_SCENE_INVALID, rl.error);
+    if (!rl.run()) return rt_fail(ctx, RT_ERR_SCENE_INVALID, rl.error);
 
     // normals, verbatim, indexed by original triangle
     std::vector<DevNrm> nrms(T);
@@ -945,8 +878,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
 
 int rt_resize(rt_ctx* ctx, int width, int height)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
-    if (width <= 0 || height <= 0 || width > 65536 || height > 65536) return fail(ctx, RT_ERR_INVALID_ARG, "image size out of range");
+    if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (width <= 0 || height <= 0 || width > 65536 || height > 65536) return rt_fail(ctx, RT_ERR_INVALID_ARG, "image size out of range");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     freeImages(ctx);
@@ -964,7 +897,7 @@ int rt_resize(rt_ctx* ctx, int width, int height)
 
 int rt_bind_images(rt_ctx* ctx, void* draw_dev, void* accum_dev, int width, int height)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!draw_dev && !accum_dev) {
@@ -973,8 +906,8 @@ int rt_bind_images(rt_ctx* ctx, void* draw_dev, void* accum_dev, int width, int 
         if (!ctx->ownDraw) ctx->width = ctx->height = 0;
         return RT_OK;
     }
-    if (!draw_dev || !accum_dev || width <= 0 || height <= 0) return fail(ctx, RT_ERR_INVALID_ARG, "rt_bind_images: need both images and a size");
-    if (((uintptr_t)draw_dev & 15) || ((uintptr_t)accum_dev & 15)) return fail(ctx, RT_ERR_INVALID_ARG, "images must be 16-byte aligned");
+    if (!draw_dev || !accum_dev || width <= 0 || height <= 0) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_bind_images: need both images and a size");
+    if (((uintptr_t)draw_dev & 15) || ((uintptr_t)accum_dev & 15)) return rt_fail(ctx, RT_ERR_INVALID_ARG, "images must be 16-byte aligned");
     freeImages(ctx);
     ctx->draw = draw_dev;
     ctx->accum = accum_dev;
@@ -985,8 +918,8 @@ int rt_bind_images(rt_ctx* ctx, void* draw_dev, void* accum_dev, int width, int 
 
 int rt_clear_accumulation(rt_ctx* ctx)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
-    if (!ctx->accum) return fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
+    if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx->accum) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipMemsetAsync(ctx->accum, 0, (size_t)ctx->width * ctx->height * 16, ctx->stream));
     return RT_OK;
@@ -996,7 +929,7 @@ int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, 
 {
     int rc = checkRenderable(ctx, pc);
     if (rc != RT_OK) return rc;
-    if (count < 0 || stride < 1) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_frames: count must be >= 0 and stride >= 1");
+    if (count < 0 || stride < 1) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_render_frames: count must be >= 0 and stride >= 1");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipEventRecord(ctx->evStart, ctx->stream));
     rt_push_constants p = *pc;
@@ -1017,13 +950,13 @@ int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, 
 
 int rt_render_frame(rt_ctx* ctx, const rt_push_constants* pc)
 {
-    if (!pc) return fail(ctx, RT_ERR_INVALID_ARG, "null push constants");
+    if (!pc) return rt_fail(ctx, RT_ERR_INVALID_ARG, "null push constants");
     return rt_render_frames(ctx, pc, pc->frame, 1, 1);
 }
 
 int rt_sync(rt_ctx* ctx)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
@@ -1031,11 +964,11 @@ int rt_sync(rt_ctx* ctx)
 
 int rt_read_image(rt_ctx* ctx, int which, float* dst, size_t bytes)
 {
-    if (!ctx || !dst) return fail(ctx, RT_ERR_INVALID_ARG, "rt_read_image: null argument");
-    if (!ctx->draw || !ctx->accum) return fail(ctx, RT_ERR_NO_IMAGES, "no images");
-    if (which != RT_IMAGE_DRAW && which != RT_IMAGE_ACCUM) return fail(ctx, RT_ERR_INVALID_ARG, "which must be 0 (draw) or 1 (accum)");
+    if (!ctx || !dst) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_read_image: null argument");
+    if (!ctx->draw || !ctx->accum) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images");
+    if (which != RT_IMAGE_DRAW && which != RT_IMAGE_ACCUM) return rt_fail(ctx, RT_ERR_INVALID_ARG, "which must be 0 (draw) or 1 (accum)");
     const size_t need = (size_t)ctx->width * ctx->height * 16;
-    if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARG, "rt_read_image: bytes must be exactly width*height*16 = " + std::to_string(need));
+    if (bytes != need) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_read_image: bytes must be exactly width*height*16 = " + std::to_string(need));
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipMemcpyAsync(dst, which == RT_IMAGE_DRAW ? ctx->draw : ctx->accum, need, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1044,10 +977,10 @@ int rt_read_image(rt_ctx* ctx, int which, float* dst, size_t bytes)
 
 int rt_write_accum(rt_ctx* ctx, const float* src, size_t bytes)
 {
-    if (!ctx || !src) return fail(ctx, RT_ERR_INVALID_ARG, "rt_write_accum: null argument");
-    if (!ctx->accum) return fail(ctx, RT_ERR_NO_IMAGES, "no images");
+    if (!ctx || !src) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_write_accum: null argument");
+    if (!ctx->accum) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images");
     const size_t need = (size_t)ctx->width * ctx->height * 16;
-    if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARG, "rt_write_accum: bytes must be exactly width*height*16");
+    if (bytes != need) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_write_accum: bytes must be exactly width*height*16");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipMemcpyAsync(ctx->accum, src, need, hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1056,13 +989,13 @@ int rt_write_accum(rt_ctx* ctx, const float* src, size_t bytes)
 
 int rt_resolve(rt_ctx* ctx, int total_frames)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
-    if (!ctx->draw || !ctx->accum) return fail(ctx, RT_ERR_NO_IMAGES, "no images");
-    if (total_frames < 1) return fail(ctx, RT_ERR_INVALID_ARG, "total_frames must be >= 1");
+    if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx->draw || !ctx->accum) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images");
+    if (total_frames < 1) return rt_fail(ctx, RT_ERR_INVALID_ARG, "total_frames must be >= 1");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     auto fn = ctx->optFast ? rt_launch_resolve_fast : rt_launch_resolve_strict;
     hipError_t e = fn(ctx->accum, ctx->draw, (size_t)ctx->width * ctx->height, 1.0f / (float)total_frames, ctx->stream);
-    if (e != hipSuccess) return failHip(ctx, e, "resolve launch");
+    if (e != hipSuccess) return rt_fail_hip(ctx, e, "resolve launch");
     return RT_OK;
 }
 
@@ -1070,7 +1003,7 @@ int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_st
 {
     int rc = checkRenderable(ctx, pc);
     if (rc != RT_OK) return rc;
-    if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "null stats pointer");
+    if (!out) return rt_fail(ctx, RT_ERR_INVALID_ARG, "null stats pointer");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipMemsetAsync(ctx->dCounters, 0, sizeof(DevCounters), ctx->stream));
     if ((rc = launchFrame(ctx, *pc, true)) != RT_OK) return rc;
@@ -1088,7 +1021,7 @@ int rt_frame_stats_noalloc(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_st
 {
     int rc = checkRenderable(ctx, pc);
     if (rc != RT_OK) return rc;
-    if (!out_dev) return fail(ctx, RT_ERR_INVALID_ARG, "null stats pointer");
+    if (!out_dev) return rt_fail(ctx, RT_ERR_INVALID_ARG, "null stats pointer");
     static_assert(sizeof(rt_frame_stats) == sizeof(DevCounters), "rt_frame_stats and DevCounters share one layout");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     {
@@ -1097,21 +1030,21 @@ int rt_frame_stats_noalloc(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_st
         hipError_t e = hipPointerGetAttributes(&at, out_dev);
         if (e != hipSuccess) (void)hipGetLastError();
         if (e != hipSuccess || !(at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged))
-            return fail(ctx, RT_ERR_INVALID_ARG, "rt_frame_stats_noalloc: out_dev must be device memory or pinned host memory");
+            return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_frame_stats_noalloc: out_dev must be device memory or pinned host memory");
     }
     const DevLaunch L = makeLaunch(ctx);
     const long long waves = (long long)L.ownedTiles * (L.tileSize / 8) * (L.tileSize / 8);
     if (waves > rt_noalloc_max_waves())
-        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_frame_stats_noalloc: this dispatch needs " + std::to_string(waves) +
+        return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rt_frame_stats_noalloc: this dispatch needs " + std::to_string(waves) +
                                                  " per-wave counter slots, the static scratch array holds " +
                                                  std::to_string(rt_noalloc_max_waves()) + " (use rt_frame_stats_compute)");
     void* slots = rt_noalloc_scratch(ctx->device);
-    if (!slots) return fail(ctx, RT_ERR_HIP, "rt_frame_stats_noalloc: the scratch array was not set up on this device");
+    if (!slots) return rt_fail(ctx, RT_ERR_HIP, "rt_frame_stats_noalloc: the scratch array was not set up on this device");
     // always the lock-step counting kernel: the other pipelines' counting passes use allocated queues
     auto fn = ctx->optFast ? rt_launch_megakernel_fast : rt_launch_megakernel_strict;
     hipError_t e = fn(&ctx->scene, pc, &L, ctx->accum, ctx->draw, static_cast<DevCounters*>(slots), 1, 2, ctx->stream);
     if (e == hipSuccess) e = rt_noalloc_sum(slots, (int)waves, out_dev, ctx->stream);
-    if (e != hipSuccess) return failHip(ctx, e, "rt_frame_stats_noalloc launch");
+    if (e != hipSuccess) return rt_fail_hip(ctx, e, "rt_frame_stats_noalloc launch");
     return RT_OK;
 }
 
@@ -1119,9 +1052,9 @@ int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16]
 {
     int rc = checkRenderable(ctx, pc);
     if (rc != RT_OK) return rc;
-    if (!out) return fail(ctx, RT_ERR_INVALID_ARG, "null output pointer");
+    if (!out) return rt_fail(ctx, RT_ERR_INVALID_ARG, "null output pointer");
     if (ctx->optPipeline != 1 || !(pc->renderMode == 0) || pc->raysPerPixel < 1)
-        return fail(ctx, RT_ERR_UNSUPPORTED, "schedule statistics exist for pipeline 1, render mode 0 only");
+        return rt_fail(ctx, RT_ERR_UNSUPPORTED, "schedule statistics exist for pipeline 1, render mode 0 only");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     unsigned long long* d = ctx->dQueue + 8;   // the queue allocation is 256 bytes: counter + 16 statistics words
     RT_HIP(ctx, hipMemsetAsync(d, 0, 16 * sizeof(unsigned long long), ctx->stream));
@@ -1133,8 +1066,8 @@ int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16]
 
 int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_frame)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
-    if (!ctx->timed) return fail(ctx, RT_ERR_INVALID_ARG, "nothing has been rendered on this stream yet");
+    if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx->timed) return rt_fail(ctx, RT_ERR_INVALID_ARG, "nothing has been rendered on this stream yet");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipEventSynchronize(ctx->evStop));
     float ms = 0.0f;
@@ -1146,7 +1079,7 @@ int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_frame)
 
 int rt_image_size(rt_ctx* ctx, int* width, int* height)
 {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID_ARG, "null context");
+    if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (width) *width = ctx->width;
     if (height) *height = ctx->height;
     return RT_OK;
@@ -1154,8 +1087,8 @@ int rt_image_size(rt_ctx* ctx, int* width, int* height)
 
 int rt_save_png(rt_ctx* ctx, const char* path)
 {
-    if (!ctx || !path) return fail(ctx, RT_ERR_INVALID_ARG, "rt_save_png: null argument");
-    if (!ctx->draw) return fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
+    if (!ctx || !path) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_save_png: null argument");
+    if (!ctx->draw) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
     const size_t pixels = (size_t)ctx->width * (size_t)ctx->height;
     std::vector<float> f(pixels * 4);
     int rc = rt_read_image(ctx, RT_IMAGE_DRAW, f.data(), f.size() * sizeof(float));
@@ -1163,13 +1096,13 @@ int rt_save_png(rt_ctx* ctx, const char* path)
     std::vector<uint8_t> b(pixels * 4);
     rt_rgba32f_to_rgba8(f.data(), b.data(), pixels);
     rc = rt_write_png_rgba8(path, b.data(), ctx->width, ctx->height);
-    if (rc != RT_OK) return fail(ctx, rc, std::string("cannot write ") + path);
+    if (rc != RT_OK) return rt_fail(ctx, rc, std::string("cannot write ") + path);
     return RT_OK;
 }
 
 int rt_produce_render(rt_ctx* ctx, rt_push_constants* pc, int render_frames, const char* png_path, double* seconds)
 {
-    if (!ctx || !pc) return fail(ctx, RT_ERR_INVALID_ARG, "rt_produce_render: null argument");
+    if (!ctx || !pc) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_produce_render: null argument");
     const auto t0 = std::chrono::system_clock::now();
     const int first = pc->frame;
     if (render_frames > first) {
@@ -1185,7 +1118,7 @@ int rt_produce_render(rt_ctx* ctx, rt_push_constants* pc, int render_frames, con
 
 int rt_math_apply(rt_ctx* ctx, int which, const float* x, float* y, size_t n)
 {
-    if (!ctx || (n && (!x || !y)) || which < 0 || which > 3) return fail(ctx, RT_ERR_INVALID_ARG, "rt_math_apply: bad argument");
+    if (!ctx || (n && (!x || !y)) || which < 0 || which > 3) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_math_apply: bad argument");
     if (n == 0) return RT_OK;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     float *dx = nullptr, *dy = nullptr;
@@ -1197,7 +1130,7 @@ int rt_math_apply(rt_ctx* ctx, int which, const float* x, float* y, size_t n)
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(dx);
     if (dy) (void)hipFree(dy);
-    if (e != hipSuccess) return failHip(ctx, e, "rt_math_apply");
+    if (e != hipSuccess) return rt_fail_hip(ctx, e, "rt_math_apply");
     return RT_OK;
 }
 

@@ -39,6 +39,18 @@
 #define RT_SYM(name) name##_strict
 #endif
 
+// Diagnostic build only (-DRT_SECTION_TIMERS): wave-level cycle counts per section of the lock-step
+// kernel, summed over all waves. No such code exists in the normal build.
+#ifdef RT_SECTION_TIMERS
+__device__ unsigned long long g_sectionCycles[8];
+__device__ __noinline__ unsigned* rt_sec_lds() { __shared__ unsigned a[8]; return a; }
+#define RT_SEC_BEGIN(t) const unsigned t = (unsigned)__builtin_amdgcn_s_memtime()
+#define RT_SEC_END(k, t) do { unsigned* a_ = rt_sec_lds(); a_[k] += (unsigned)__builtin_amdgcn_s_memtime() - (t); } while (0)
+#else
+#define RT_SEC_BEGIN(t) do { } while (0)
+#define RT_SEC_END(k, t) do { } while (0)
+#endif
+
 namespace {
 
 struct V3 { float x, y, z; };
@@ -367,6 +379,7 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
     best.object = -1;
     best.tri = 0; best.u = 0.0f; best.v = 0.0f; best.tLocal = 0.0f;
     if (COUNT) cnt.rays++;
+    RT_SEC_BEGIN(secTrace);
 
     V3 winv;
     const bool parW = lean_inverse(dirN, winv);
@@ -375,6 +388,7 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
     // accepted hit, so which triangles it can reach does not depend on the visiting order: it
     // may take the cheap leaf parents first. (Only when the dispatch covers every uploaded parent.)
     const bool permute = ANYHIT && parentCount == S.objectCount;
+    const bool tightScene = !COUNT && S.nearFirstBase != 0x7fffffff;   // the near-first scene (wave-uniform)
     for (int pos = 0; pos < parentCount; ++pos) {
         const int i = permute ? S.anyOrder[pos] : pos;
         const DevObject* ob = S.objects + i;   // wave-uniform address
@@ -383,12 +397,16 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
         float E;
         bool ok = (__any(parW) ? lean_box<true>(org, winv, bmn, bmx, tMin, E) : lean_box<false>(org, winv, bmn, bmx, tMin, E)) &&
                   (best.closest > E);
-        if (ok) ok = !(distance_to_aabb(org, bmn, bmx) > best.closest);
+        // (the point-to-box distance is never larger than the entry distance E, so this cull of
+        // raytrace.comp:469-471 can only fire on a rounding tie: the near-first scene, whose boxes are only
+        // culls, leaves it out)
+        if (ok && !tightScene) ok = !(distance_to_aabb(org, bmn, bmx) > best.closest);
         const int root = ob->root;   // wave-uniform
         if (root < 0) {
             // A parent that is one leaf (a wall: two triangles): every lane that enters tests the same
             // triangles, so their records come through the scalar cache, once for the wave.
             if (!(root > RT_REF_LIVE_MIN) || !__any(ok)) continue;
+            RT_SEC_BEGIN(secLeaf);
             V3 lo = xform(ob->inv, org, 1.0f);
             V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
             const float4* tp = reinterpret_cast<const float4*>(S.tris + ~root);
@@ -403,6 +421,7 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
                 if (__float_as_int(t0.w) <= 1) break;
                 tp += 3;
             }
+            RT_SEC_END(2, secLeaf);
             continue;
         }
         int cur = root;
@@ -410,6 +429,7 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
         // a root in the rebuilt part of the record array: this object's tree may be walked nearer
         // child first (wave-uniform)
         const bool nearFirst = !COUNT && root >= S.nearFirstBase;
+        RT_SEC_BEGIN(secWalk);
 
         V3 lo = xform(ob->inv, org, 1.0f);
         V3 ld = normalize3(xform(ob->inv, dirN, 0.0f));
@@ -477,7 +497,9 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
             }
             if (cur == RT_NONE) break;
         }
+        RT_SEC_END(3, secWalk);
     }
+    RT_SEC_END(1, secTrace);
     return best.object >= 0;
 }
 
@@ -650,7 +672,9 @@ __device__ __forceinline__ V3 ray_colour(const DevScene& S, const rt_push_consta
         Best best;
         trace<COUNT, false>(S, pc.parentBVHCount, ray.o, dirN, 0.001f, 1e20f, best, cnt, stack);
         HitRec rec;
+        RT_SEC_BEGIN(secFinish);
         finish_hit(S, ray.o, dirN, best, rec);
+        RT_SEC_END(4, secFinish);
         if (!rec.hit) {
             result = result + throughput * environment_colour(pc, ray.d);
             break;
@@ -682,7 +706,9 @@ __device__ __forceinline__ V3 ray_colour(const DevScene& S, const rt_push_consta
         }
         V3 attenuation;
         Ray scattered;
+        RT_SEC_BEGIN(secScatter);
         material_scatter(m, ray.d, rec, seed, attenuation, scattered);
+        RT_SEC_END(5, secScatter);
         throughput = throughput * attenuation;
         ray = scattered;
     }
@@ -727,6 +753,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
     V3 winvA, winvB;
     const bool parWA = lean_inverse(dA, winvA) && onA, parWB = lean_inverse(dB, winvB) && onB;
     const bool permute = ANYHIT && parentCount == S.objectCount;
+    const bool tightScene = S.nearFirstBase != 0x7fffffff;   // the near-first scene: boxes are only culls
     for (int pos = 0; pos < parentCount; ++pos) {
         const int i = permute ? S.anyOrder[pos] : pos;
         const DevObject* ob = S.objects + i;   // wave-uniform address
@@ -736,10 +763,10 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
         float E;
         bool okA = liveA && (__any(parWA) ? lean_box<true>(oA, winvA, bmn, bmx, tMin, E) : lean_box<false>(oA, winvA, bmn, bmx, tMin, E)) &&
                    (bA.closest > E);
-        if (okA) okA = !(distance_to_aabb(oA, bmn, bmx) > bA.closest);
+        if (okA && !tightScene) okA = !(distance_to_aabb(oA, bmn, bmx) > bA.closest);
         bool okB = liveB && (__any(parWB) ? lean_box<true>(oB, winvB, bmn, bmx, tMin, E) : lean_box<false>(oB, winvB, bmn, bmx, tMin, E)) &&
                    (bB.closest > E);
-        if (okB) okB = !(distance_to_aabb(oB, bmn, bmx) > bB.closest);
+        if (okB && !tightScene) okB = !(distance_to_aabb(oB, bmn, bmx) > bB.closest);
         const int root = ob->root;   // wave-uniform
         if (!(root > RT_REF_LIVE_MIN) || !__any(okA || okB)) continue;
         if (root < 0) {
@@ -897,7 +924,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT
     const int ownedTile = blockIdx.x / wavesPerTile;
     const int sub = blockIdx.x - ownedTile * wavesPerTile;
     const int tile = L.tileRank + ownedTile * L.tileWorld;
-    const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
+    int tx, ty;
+    rt_tile_of_position(tile, L.tilesX, &tx, &ty);
     const int sy = sub / wavesX, sx = sub - sy * wavesX;
     const int x = tx * L.tileSize + sx * 8 + (lane & 7);
     const int y = ty * L.tileSize + sy * 8 + (lane >> 3);
@@ -906,6 +934,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT
     Counters cnt;
     cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0;
     int samples = 0;
+#ifdef RT_SECTION_TIMERS
+    if (lane < 8) rt_sec_lds()[lane] = 0;
+    __syncthreads();
+#endif
+    RT_SEC_BEGIN(secKernel);
 
     if (inside) {
         const size_t idx = (size_t)y * (size_t)L.width + (size_t)x;
@@ -985,6 +1018,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT
         }
     }
 
+#ifdef RT_SECTION_TIMERS
+    __syncthreads();
+    if (lane == 0) {
+        unsigned* a = rt_sec_lds();
+        a[0] = (unsigned)__builtin_amdgcn_s_memtime() - secKernel;
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_sectionCycles[k], (unsigned long long)a[k]);
+    }
+#endif
     if (COUNT && counters != nullptr) {
         int r = wave_sum(cnt.rays), n = wave_sum(cnt.nodeTests), t = wave_sum(cnt.triTests), s = wave_sum(samples);
         if (lane == 0 && statsOnly == 2) {
@@ -1017,7 +1058,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT
     const int ownedTile = blockIdx.x / wavesPerTile;
     const int sub = blockIdx.x - ownedTile * wavesPerTile;
     const int tile = L.tileRank + ownedTile * L.tileWorld;
-    const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
+    int tx, ty;
+    rt_tile_of_position(tile, L.tilesX, &tx, &ty);
     const int sy = sub / wavesX, sx = sub - sy * wavesX;
     const int x = tx * L.tileSize + sx * 8 + (lane & 7);
     const int y = ty * L.tileSize + sy * 8 + (lane >> 3);
@@ -1369,7 +1411,8 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_schedkernel)(DevScene S, rt_push
                             const unsigned ownedTile = (unsigned)(idx / pixelsPerTile);
                             const unsigned local = (unsigned)(idx - (unsigned long long)ownedTile * pixelsPerTile);
                             const int tile = L.tileRank + (int)ownedTile * L.tileWorld;
-                            const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
+                            int tx, ty;
+    rt_tile_of_position(tile, L.tilesX, &tx, &ty);
                             const int sub = (int)(local >> 6), l = (int)(local & 63u);
                             const int sy = sub / wavesX, sx = sub - sy * wavesX;
                             px = tx * L.tileSize + sx * 8 + (l & 7);
@@ -1762,7 +1805,8 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_path)(DevScene S, rt_push_con
             const int ownedTile = (int)chunk / wavesPerTile;
             const int sub = (int)chunk - ownedTile * wavesPerTile;
             const int tile = L.tileRank + ownedTile * L.tileWorld;
-            const int ty = tile / L.tilesX, tx = tile - ty * L.tilesX;
+            int tx, ty;
+    rt_tile_of_position(tile, L.tilesX, &tx, &ty);
             const int sy = sub / wavesX, sx = sub - sy * wavesX;
             px = tx * L.tileSize + sx * 8 + (lane & 7);
             py = ty * L.tileSize + sy * 8 + (lane >> 3);
@@ -2166,6 +2210,18 @@ __global__ __launch_bounds__(256) void RT_SYM(rt_math_kernel)(int which, const f
 }
 
 // ---- launchers (called from rt_host.cpp) ---------------------------------------
+
+#if defined(RT_SECTION_TIMERS) && defined(RT_FLAVOUR_STRICT)
+// diagnostic build: read (and clear) the per-section cycle sums of the lock-step kernel
+extern "C" int rt_debug_sections(unsigned long long out[8])
+{
+    unsigned long long zero[8] = { 0 };
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sectionCycles), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_sectionCycles), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 extern "C" hipError_t RT_SYM(rt_launch_megakernel)(const DevScene* S, const rt_push_constants* pc, const DevLaunch* L,
                                                    void* accum, void* out, DevCounters* counters, int countBuild,

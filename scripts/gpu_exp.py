@@ -19,11 +19,12 @@ pc = R.default_push_constants(); R.camera_to_push_constants(R.default_camera(), 
 for name, keep in (("full", list(range(8))), ("walls only", [2, 3, 4, 5, 6, 7]), ("dragon+ico only", [0, 1]), ("dragon+walls", [1,2,3,4,5,6,7]), ("walls then dragon+ico", [2,3,4,5,6,7,0,1])):
     a = variant(keep)
     r.upload_scene(a); pc.parentBVHCount = len(keep)
-    for pipe in (0, 1):
+    for pipe, trav in ((3, 0), (3, 1), (0, 1)):
         r.set_option(R.RT_OPT_PIPELINE, pipe)
+        r.set_option(R.RT_OPT_TRAVERSAL, trav)
         r.render_frames(pc, 0, 1, 2); r.sync()
         r.render_frames(pc, 0, 1, 6); r.sync()
         ms = r.last_render_ms()[1]
         pc.frame = 0
         st = r.frame_stats(pc)
-        print("%-22s pipeline %d: %.2f ms/frame  rays %d node %d tri %d  -> %.0f Mrays/s" % (name, pipe, ms, st.rays, st.bvhNodeTests, st.triangleTests, st.rays / ms / 1e3))
+        print("%-22s pipeline %d trav %d: %.2f ms/frame  rays %d node %d tri %d  -> %.0f Mrays/s" % (name, pipe, trav, ms, st.rays, st.bvhNodeTests, st.triangleTests, st.rays / ms / 1e3))

@@ -34,12 +34,11 @@ class OracleTarget:
 
     def render_frames(self, first, stride, count):
         rank, world, ts = self.tiles
-        tx = (W + ts - 1) // ts
         for k in range(count):
             self.opc["frame"] = first + k * stride
             acc = self.accum.numpy()
-            for t in D.tiles_of_rank(rank, world, W, H, ts):
-                x0, y0 = (t % tx) * ts, (t // tx) * ts
+            for tile_x, tile_y in D.tiles_of_rank(rank, world, W, H, ts):
+                x0, y0 = tile_x * ts, tile_y * ts
                 r = O.render(self.arrays, O.pc_bytes(self.opc), W, H, accum=acc, window=(x0, y0, x0 + ts, y0 + ts), nthreads=2)
                 acc = r["accum"]
                 self.draw.numpy()[y0:y0 + ts, x0:x0 + ts] = r["out"][y0:y0 + ts, x0:x0 + ts]
@@ -83,7 +82,15 @@ def test_partitions_cover_everything_once():
         frames = sorted(f for r in range(world) for f in D.frames_of_rank(r, world, 5))
         assert frames == list(range(5 * world))
         tiles = sorted(t for r in range(world) for t in D.tiles_of_rank(r, world, 200, 120, 32))
-        assert tiles == list(range(7 * 4))
+        assert tiles == sorted((x, y) for x in range(7) for y in range(4))
+        owner = D.tile_owner_map(world, 200, 120, 32)
+        for r in range(world):
+            for x, y in D.tiles_of_rank(r, world, 200, 120, 32):
+                assert (owner[y * 32:(y + 1) * 32, x * 32:(x + 1) * 32] == r).all()
+    # serpentine numbering: consecutive numbers are neighbouring tiles
+    path = [D.tile_of_position(p, 7) for p in range(28)]
+    assert path[:8] == [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (6, 0), (6, 1)]
+    assert all(abs(a[0] - b[0]) + abs(a[1] - b[1]) == 1 for a, b in zip(path, path[1:]))
 
 
 def test_two_rank_gloo_sample_and_tile_split(tmp_path, default_scene_arrays):
@@ -119,7 +126,10 @@ def test_two_rank_gloo_sample_and_tile_split(tmp_path, default_scene_arrays):
 
 def _gpu_worker(rank, world, port, out_dir):
     """Two processes that share cuda:0 (a rehearsal: RCCL wants one GPU per rank, so the collective
-    goes over gloo here; the drivers and the kernels are the ones an 8-GPU run uses)."""
+    goes over gloo here, through a pinned host copy; the drivers and the kernels are the ones an 8-GPU
+    run uses)."""
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)     # a stuck collective ends the worker with a traceback
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -148,10 +158,6 @@ def _gpu_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("RT_TEST_SHARED_GPU") != "1",
-                    reason="two processes sharing one GPU: gloo collectives on device tensors hang now and then in that setting "
-                           "(both ranks inside all_reduce, any kernel choice; seen with bench.py --share-gpu 1 as well), which says "
-                           "nothing about one process per GPU. Set RT_TEST_SHARED_GPU=1 to run it.")
 def test_two_ranks_on_one_gpu_sample_and_tile_split(tmp_path):
     import raytracer_amd as R
     world, Wg, Hg = 2, 160, 96
@@ -206,7 +212,20 @@ def _rccl_worker(rank, world, port, out_dir):
     D.render_tile_split(tgt, frames=3, tile_size=32, always_reduce=True)
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, "n_ts_acc.npy"), tgt.accum.cpu().numpy())
+    # the same through the library's own communicator (rt_comm_init / rt_merge_accum / rt_gather_tiles)
+    tgt.init_comm()
+    assert tgt.native_comm and r.comm_info() == (0, 1)
+    for k in range(2):
+        D.render_sample_split(tgt, frames_per_rank=3, always_reduce=True)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, "c_ss_acc.npy"), tgt.accum.cpu().numpy())
+    np.save(os.path.join(out_dir, "c_ss_out.npy"), tgt.draw.cpu().numpy())
+    D.render_tile_split(tgt, frames=3, tile_size=32, always_reduce=True)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, "c_ts_acc.npy"), tgt.accum.cpu().numpy())
+    np.save(os.path.join(out_dir, "c_ts_out.npy"), tgt.draw.cpu().numpy())
     tgt.close()
+    assert r.comm_info() == (0, 0)
     r.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -229,3 +248,63 @@ def test_rccl_all_reduce_on_the_target_stream(tmp_path):
     assert np.array_equal(np.load(tmp_path / "n_ss_acc.npy").view(np.uint32), acc.view(np.uint32))
     assert np.array_equal(np.load(tmp_path / "n_ss_out.npy")[..., :3].view(np.uint32), out[..., :3].view(np.uint32))
     assert np.array_equal(np.load(tmp_path / "n_ts_acc.npy").view(np.uint32), acc.view(np.uint32))
+    assert np.array_equal(np.load(tmp_path / "c_ss_acc.npy").view(np.uint32), acc.view(np.uint32))
+    assert np.array_equal(np.load(tmp_path / "c_ss_out.npy")[..., :3].view(np.uint32), out[..., :3].view(np.uint32))
+    assert np.array_equal(np.load(tmp_path / "c_ts_acc.npy").view(np.uint32), acc.view(np.uint32))
+    assert np.array_equal(np.load(tmp_path / "c_ts_out.npy").view(np.uint32), out.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,size,tile", [(2, (200, 120), 32), (3, (333, 187), 64), (8, (520, 200), 16)])
+def test_local_merges_between_contexts(world, size, tile):
+    """rt_gather_tiles_local / rt_merge_accum_local: `world` contexts on one GPU play the ranks. The tile
+    exchange (pack kernel, the copies an all-gather performs, unpack kernel - the kernels rt_gather_tiles
+    uses) must complete every context's images to the single-context render bit for bit; the sample merge
+    must give the rank-ordered sum on every context."""
+    import raytracer_amd as R
+    Wg, Hg = size
+    s = R.Scene(); s.init_default()
+    pc = R.default_push_constants(); R.camera_to_push_constants(R.default_camera(), Wg, Hg, pc); pc.parentBVHCount = 8
+    rs = [R.Renderer(0) for _ in range(world)]
+    try:
+        for r in rs:
+            r.upload_scene(s.buffers()); r.resize(Wg, Hg)
+        ref = R.Renderer(0)
+        ref.upload_scene(s.buffers()); ref.resize(Wg, Hg)
+        ref.render_frames(pc, 0, 1, 3)
+        want_acc, want_out = ref.read_image(R.RT_IMAGE_ACCUM), ref.read_image(R.RT_IMAGE_DRAW)
+        for rank, r in enumerate(rs):
+            r.set_option(R.RT_OPT_TILE_SIZE, tile); r.set_option(R.RT_OPT_TILE_WORLD, world); r.set_option(R.RT_OPT_TILE_RANK, rank)
+            r.render_frames(pc, 0, 1, 3)
+        owner = D.tile_owner_map(world, Wg, Hg, tile)
+        before = rs[1].read_image(R.RT_IMAGE_ACCUM)
+        assert np.array_equal(before[owner == 1].view(np.uint32), want_acc[owner == 1].view(np.uint32))
+        assert not before[owner != 1].any()
+        R.gather_tiles_local(rs)
+        for r in rs:
+            assert np.array_equal(r.read_image(R.RT_IMAGE_ACCUM).view(np.uint32), want_acc.view(np.uint32))
+            assert np.array_equal(r.read_image(R.RT_IMAGE_DRAW).view(np.uint32), want_out.view(np.uint32))
+        # sample split: rank r renders frames r, r + world, ...; merged = ((a0 + a1) + a2) + ...
+        parts = []
+        for rank, r in enumerate(rs):
+            r.set_option(R.RT_OPT_TILE_WORLD, 1); r.set_option(R.RT_OPT_TILE_RANK, 0)
+            r.clear_accumulation()
+            r.render_frames(pc, rank, world, 2)
+            parts.append(r.read_image(R.RT_IMAGE_ACCUM))
+        R.merge_accum_local(rs)
+        total = parts[0]
+        for p in parts[1:]:
+            total = total + p
+        for r in rs:
+            assert np.array_equal(r.read_image(R.RT_IMAGE_ACCUM).view(np.uint32), total.view(np.uint32))
+        ref.clear_accumulation()
+        ref.render_frames(pc, 0, 1, 2 * world)
+        np.testing.assert_allclose(total[..., :3], ref.read_image(R.RT_IMAGE_ACCUM)[..., :3], rtol=1e-5, atol=1e-6)
+        # mismatched partition options are refused
+        rs[0].set_option(R.RT_OPT_TILE_WORLD, 5)
+        with pytest.raises(R.RtError):
+            R.gather_tiles_local(rs)
+        ref.close()
+    finally:
+        for r in rs:
+            r.close()

@@ -319,8 +319,8 @@ def test_tile_partition_is_bit_identical(R, rdr, default_scene_arrays):
             touched = np.any(bits(acc) != 0, axis=2) | np.any(bits(out) != 0, axis=2)
             owner += touched
             sum_acc += acc
-            ty, tx = np.mgrid[0:H, 0:W]
-            mine = ((ty // 32) * ((W + 31) // 32) + tx // 32) % world == rank
+            from raytracer_amd.distributed import tile_owner_map
+            mine = tile_owner_map(world, W, H, 32) == rank      # tiles are dealt along a serpentine path
             assert not np.any(touched & ~mine)
             assert np.array_equal(bits(acc[mine]), bits(full_acc[mine]))
             assert np.array_equal(bits(out[mine]), bits(full_out[mine]))
