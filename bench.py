@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-Workload at N=1 (BASELINE.json configs[1]): the reference's default scene at 2560x1369, 64 spp
-as 64 progressively accumulated frames of 1 ray/pixel, shipped bounce count. One "step" is
-that whole 64-frame render: clear the accumulation image, 64 dispatches.
+Default workload (BASELINE.json configs[1]): the reference's default scene at 2560x1369, 64 spp as 64
+progressively accumulated frames of 1 ray/pixel, shipped bounce count. One "step" is that whole render:
+clear the accumulation image, the dispatches, (N > 1: one merge), resolve. Scene and images are resident
+in HBM before timing starts.
 
-N>1 (sample split, weak scaling): every rank renders 64 frames of its own (rank r takes frames
-r, r+N, r+2N, ...), so the image gets 64*N spp; the accumulation images are then summed with
-one RCCL all-reduce and resolved. Scene and images are resident in HBM before timing starts.
+  --config 1   default scene 2560x1369, 64 frames             (headline; N > 1: sample split)
+  --config 2   generated 100 352-triangle height field, 1920x1080, 16 frames
+  --config 3   default scene 3840x2160, 1024 frames           (N > 1: sample split; use --scaling strong)
+  --config 4s  generated 999 424-triangle mixed-material scene, 1920x1080, 16 frames (N > 1: tile split)
+  --scaling weak    every rank renders the config's frame count (sample split) - N GPUs give N times the spp
+  --scaling strong  the config's frames are divided among the ranks (frames / N each)
+  (tile split always divides the image, i.e. is strong scaling)
 
-metric: Mrays/s, where a ray is one GetHit call of the reference shader (primary, bounce or
-shadow ray); the ray count of every frame is taken by an untimed counting pass.
+metric: Mrays/s, where a ray is one GetHit call of the reference shader (primary, bounce or shadow ray),
+counted by an untimed pass of the counting kernel, which walks the reference's trees in the reference's
+order - so the number is the reference's work per second, whatever the timed kernel skips.
+
+Two traversal flavours are timed in the same run (N = 1): "near-first" (RT_OPT_TRAVERSAL 1: rebuilt SAH
+trees, nearer child first; within the stated tolerance of the oracle, > 99.99 % of pixels bit-identical)
+is the headline, "reference-order" (RT_OPT_TRAVERSAL 0: bit-exact with the oracle) is reported beside it.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,21 +41,48 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak (spec)
 VALU_PEAK_TFLOPS = 157.3        # MI355X FP32 vector peak (spec)
 
 
-def cpu_baseline(arrays, pc_bytes_fn, W, H, seconds, threads):
+class Watchdog:
+    """Ends the process with a non-zero status when a stage does not finish in time, instead of sitting
+    in a collective for ever. (No re-exec: the process exits; a driver starts a fresh one.)"""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.deadline = None
+        self.what = ""
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def arm(self, seconds, what):
+        self.what = what
+        self.deadline = time.monotonic() + seconds
+
+    def disarm(self):
+        self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            d = self.deadline
+            if d is not None and time.monotonic() > d:
+                import faulthandler
+                sys.stderr.write("[rank %d] bench.py watchdog: '%s' did not finish in time; giving up\n" % (self.rank, self.what))
+                faulthandler.dump_traceback(file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(3)
+
+
+def cpu_baseline(arrays, pc_bytes, W, H, seconds, threads, host_cpus):
     """Times the CPU oracle (a port of the reference shader, oracle/rt_oracle.c) on row bands of
-    frame 0 of the same workload until `seconds` have elapsed."""
+    frames 0, 1, ... of the same workload until `seconds` have elapsed."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
-    band = 32
-    rays = 0
-    pixels = 0
-    bands = 0
-    frame = 0
-    pc = np.frombuffer(pc_bytes_fn().tobytes(), dtype=O.PC_DTYPE).copy()
+    band = 64
+    rays = pixels = bands = frame = 0
+    pc = np.frombuffer(pc_bytes.tobytes(), dtype=O.PC_DTYPE).copy()
     t0 = time.time()
     done = False
-    while not done:                       # whole frames 0, 1, 2, ... in row bands until the budget is spent
+    while not done:
         pc["frame"] = frame
         for y0 in range(0, H, band):
             r = O.render(arrays, O.pc_bytes(pc), W, H, window=(0, y0, W, min(H, y0 + band)), counters=True, nthreads=threads)
@@ -55,9 +94,27 @@ def cpu_baseline(arrays, pc_bytes_fn, W, H, seconds, threads):
                 break
         frame += 1
     dt = time.time() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "frames 0..%d of the same workload in row bands of %d rows: %d bands, %d pixel samples, %d rays in %.1f s" % (frame - 1, band, bands, pixels, rays, dt),
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "host_cpus": host_cpus,
+            "sample": "frames 0..%d of the same workload in row bands of %d rows: %d bands, %d pixel samples, %d rays in %.1f s on %d threads "
+                      "(the box reports %d CPUs; a one-GPU job is given a share of 16)" % (frame - 1, band, bands, pixels, rays, dt, threads, host_cpus),
             "msamples_per_s": pixels / dt / 1e6}
+
+
+def measured_traffic(kernel, config, traversal, frames_per_launch):
+    """HBM bytes per launch of `kernel` from profiles/hbm_traffic.json (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE,
+    separate --pmc passes, scripts/traffic.sh). An entry only counts when it was taken from the kernel
+    source this run uses (sha256 of rt_kernels.hip) in the same configuration; otherwise None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    src = os.path.join(ROOT, "raytracer_amd", "csrc", "rt_kernels.hip")
+    try:
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+        for e in json.load(open(path)).get("entries", []):
+            if (e.get("kernel"), str(e.get("config")), e.get("traversal"), e.get("frames_per_launch"), e.get("kernels_sha256")) == \
+                    (kernel, str(config), traversal, frames_per_launch, sha):
+                return e.get("bytes_per_launch")
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -65,24 +122,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=2560)
-    ap.add_argument("--height", type=int, default=1369)
-    ap.add_argument("--spp", type=int, default=64, help="frames per step per GPU")
-    ap.add_argument("--fast", type=int, default=0, help="1 = FMA-contracted flavour (not bit-exact with the oracle)")
+    ap.add_argument("--config", default="1", choices=["1", "2", "3", "4s"], help="benchmark configuration (see the module text)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--frames", type=int, default=0, help="frames per step (per GPU when weak); 0 = the configuration's")
+    ap.add_argument("--width", type=int, default=0, help="override the image size (both or none)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--traversal", type=int, default=1, choices=[0, 1], help="headline flavour: 1 = near-first on rebuilt trees, 0 = reference order")
+    ap.add_argument("--compare", type=int, default=1, help="1 = at N = 1 also time the other traversal flavour in the same run")
+    ap.add_argument("--fast", type=int, default=0, help="1 = FMA-contracted arithmetic (not bit-exact with the oracle)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
-    ap.add_argument("--share-gpu", type=int, default=0, help="1 = every rank uses cuda:0 (rehearsal of the N > 1 flow on a one-GPU box, with --backend gloo; two processes on one GPU "
-                         "hang now and then inside gloo's all_reduce of device tensors: run it under a timeout)")
+    ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
+                    help="who merges the images for N > 1: native = rt_merge_accum / rt_gather_tiles inside librt_amd.so (RCCL), "
+                         "torch = torch.distributed; auto = native on the nccl backend")
+    ap.add_argument("--share-gpu", type=int, default=0, help="1 = every rank uses cuda:0 (rehearsal of the N > 1 flow on a one-GPU box, with --backend gloo)")
     ap.add_argument("--pipeline", type=int, default=-1, help="RT_OPT_PIPELINE to measure (-1 = the library's default)")
     ap.add_argument("--trace", type=int, default=0, help="1 = stage markers on stderr")
+    ap.add_argument("--stage-timeout", type=float, default=600.0, help="seconds a stage (set-up, warm-up, timed steps) may take before the watchdog ends the process")
     ap.add_argument("--single-dispatch", type=int, default=0,
-                    help="1 = also time 64 spp as ONE dispatch with raysPerPixel = 64 (extra launches of the same kernel: off by "
+                    help="1 = also time the frames as ONE dispatch with raysPerPixel = frames (extra launches of the same kernel: off by "
                          "default so that a profile of the default run holds only the timed launches)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import raytracer_amd as R
+    from raytracer_amd import distributed as D
+    from raytracer_amd.workloads import build_workload
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -90,6 +156,13 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     distributed = world > 1
+    dog = Watchdog(rank)
+    dog.arm(args.stage_timeout, "set-up")
+
+    def mark(what):
+        if args.trace:
+            print("[rank %d] %.3f %s" % (rank, time.time(), what), file=sys.stderr, flush=True)
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -98,18 +171,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
-
-    def mark(what):
-        if args.trace:
-            print("[rank %d] %s" % (rank, what), file=sys.stderr, flush=True)
-
-    if args.trace:
-        import faulthandler
-        faulthandler.dump_traceback_later(35, exit=False)
-    W, H, spp = args.width, args.height, args.spp
     mark("process group ready")
-    scene = R.Scene()
-    scene.init_default()
+
+    wl = build_workload(args.config)
+    W, H = (args.width, args.height) if args.width > 0 and args.height > 0 else (wl["width"], wl["height"])
+    scene, pc = wl["scene"], wl["pc"]
+    if (W, H) != (wl["width"], wl["height"]):
+        raise SystemExit("--width/--height override is only meant for quick checks; rebuild the workload's camera for another size")
     sb = scene.buffers()
     arrays = sb.to_arrays()
     r = R.Renderer(local_rank)
@@ -117,30 +185,59 @@ def main():
     r.set_option(R.RT_OPT_FAST_MATH, args.fast)
     if args.pipeline >= 0:
         r.set_option(R.RT_OPT_PIPELINE, args.pipeline)
-    pc = R.default_push_constants()
-    R.camera_to_push_constants(R.default_camera(), W, H, pc)
-    pc.parentBVHCount = 8
-    from raytracer_amd import distributed as D
+    r.set_option(R.RT_OPT_TRAVERSAL, args.traversal)
+    tile_split = args.config == "4s" and distributed
+    total_frames = args.frames if args.frames > 0 else wl["frames"]
+    if tile_split:
+        frames_rank = total_frames                       # every rank renders every frame of its tiles
+        scaling = "strong"
+    elif args.scaling == "strong" and distributed:
+        if total_frames % world:
+            raise SystemExit("--scaling strong: %d frames do not divide among %d ranks" % (total_frames, world))
+        frames_rank = total_frames // world
+        scaling = "strong"
+    else:
+        frames_rank = total_frames
+        scaling = "weak"
     target = D.GpuTarget(r, pc, W, H, dev)      # images are torch tensors, kernels run on a torch stream the target owns
-    frames = D.frames_of_rank(rank, world, spp)
+    native = distributed and (args.comm == "native" or (args.comm == "auto" and args.backend == "nccl"))
+    if native:
+        target.init_comm()
+    mark("scene uploaded, communicator %s" % ("native" if native else "torch" if distributed else "none"))
 
-    # untimed counting pass: GetHit calls and the shader's node/triangle test counters per frame
+    # untimed counting pass: GetHit calls and the shader's node/triangle test counters of this rank's
+    # share (its frames; in a tile split its tiles). Exact for up to 64 frames; longer frame sets are
+    # counted on an evenly spaced sample of 64 frames and scaled (frames differ by < 0.1 %).
+    if tile_split:
+        target.set_tiles(rank, world, 64)
+        my_frames = list(range(total_frames))
+    else:
+        my_frames = D.frames_of_rank(rank, world, frames_rank) if distributed else list(range(frames_rank))
+    counted = my_frames if len(my_frames) <= 64 else [my_frames[(k * len(my_frames)) // 64] for k in range(64)]
     rays = node = tri = 0
-    for f in frames:
+    for f in counted:
         p = pc.copy()
         p.frame = f
         st = r.frame_stats(p)
         rays += st.rays; node += st.bvhNodeTests; tri += st.triangleTests
-    mark("counting pass done")
+    scale = len(my_frames) / float(len(counted))
+    rays, node, tri = rays * scale, node * scale, tri * scale
+    if tile_split:
+        target.set_tiles(0, 1, 64)
     counts = torch.tensor([rays, node, tri], dtype=torch.float64, device=dev)
     if distributed:
-        dist.all_reduce(counts)
+        if args.backend == "nccl":
+            dist.all_reduce(counts)
+        else:
+            host = counts.cpu(); dist.all_reduce(host); counts = host
     total_rays = float(counts[0].item())
+    mark("counting pass done")
 
     def step():
-        # clear, `spp` dispatches (frames rank, rank+N, ...), one all-reduce of the accumulation
-        # image when N > 1, resolve
-        D.render_sample_split(target, spp)
+        if tile_split:
+            D.render_tile_split(target, frames_rank, 64)
+        else:
+            D.render_sample_split(target, frames_rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -148,87 +245,126 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    mark("counts reduced")
-    for _ in range(args.warmup):
-        step()
-    mark("warm-up enqueued")
-    fence()
-    mark("warm-up done")
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step()
-        mark("step %d enqueued" % k)
-        # HIP events recorded by the library around the 64 dispatches, on the stream they run on;
-        # reading them back waits only for work that is already enqueued
-        kernel_ms.append(r.last_render_ms()[0])
-        mark("step %d kernels timed" % k)
-    fence()
-    mark("timed steps done")
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if distributed:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    def timed(traversal):
+        """-> (seconds for args.steps steps, max over ranks; kernel ms per step of this rank)"""
+        r.set_option(R.RT_OPT_TRAVERSAL, traversal)
+        dog.arm(args.stage_timeout, "warm-up (traversal %d)" % traversal)
+        for _ in range(max(args.warmup, 1 if traversal != args.traversal else 0)):
+            step()
+        fence()
+        mark("warm-up done")
+        dog.arm(args.stage_timeout, "timed steps (traversal %d)" % traversal)
+        kernel_ms = []
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step()
+            # HIP events recorded by the library around the dispatches, on the stream they run on;
+            # reading them back waits only for work that is already enqueued
+            kernel_ms.append(r.last_render_ms()[0])
+            mark("step %d enqueued and its kernels timed" % k)
+        fence()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if distributed:
+            if args.backend == "nccl":
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            else:
+                host = tmax.cpu(); dist.all_reduce(host, op=dist.ReduceOp.MAX); tmax = host
+        mark("timed steps done")
+        return float(tmax.item()), float(np.mean(kernel_ms))
+
+    dt, kernel_ms = timed(args.traversal)
+    other = None
+    if world == 1 and args.compare:
+        other = timed(1 - args.traversal)
+        r.set_option(R.RT_OPT_TRAVERSAL, args.traversal)
+    dog.arm(args.stage_timeout, "reporting")
 
     if rank == 0:
+        names = {0: "reference-order", 1: "near-first"}
         ms_step = dt / args.steps * 1e3
-        # one launch of the kernel (default: rt_pairkernel, two samples per lane) renders `group` consecutive frames
-        # (RT_OPT_FRAMES_PER_LAUNCH)
-        group = r.get_option(R.RT_OPT_FRAMES_PER_LAUNCH)
-        launches = (spp + group - 1) // group
-        launch_ms = float(np.mean(kernel_ms)) / launches      # average duration of one launch of the megakernel
-        bytes_per_launch = (40.0 * node + 48.0 * tri + 48.0 * W * H * spp) / launches     # rank 0's frames
+        pipeline = r.get_option(R.RT_OPT_PIPELINE)
+        group = r.get_option(R.RT_OPT_FRAMES_PER_LAUNCH) if pipeline in (0, 3) else 1
+        launches = (frames_rank + group - 1) // group
+        kernel = {0: "rt_megakernel", 3: "rt_pairkernel" if frames_rank >= 2 else "rt_megakernel"}.get(pipeline, "pipeline %d" % pipeline)
+        kernel += "_fast" if args.fast else "_strict"
+        launch_ms = kernel_ms / launches                                  # average duration of one launch of the dominant kernel
+        pixels_rank = W * H if not tile_split else W * H / world
+        bytes_per_launch = (40.0 * node + 48.0 * tri + 48.0 * pixels_rank * frames_rank) / launches     # rank 0's share
         flops_per_launch = (21.0 * node + 45.0 * tri) / launches
-        achieved_gbps = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        alg_gbps = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        alg_tflops = flops_per_launch / (launch_ms * 1e-3) / 1e12
+        traffic = measured_traffic(kernel, args.config, args.traversal, group)
+        scene_bytes = sum(a.nbytes for a in arrays)
+        cache_resident = scene_bytes < 32 * 2 ** 20       # the 18 arrays fit the aggregate L2 (8 x 4 MiB)
+        spp_total = frames_rank * (world if not tile_split else 1)
         out = {
             "metric": "Mrays/s", "value": total_rays * args.steps / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "reference default scene (hard-coded InitializeScene: 8 objects, 8794 triangles; dragon_lowres.obj stands in for the undistributed dragon.obj)",
-            "config": {"workload": "configs[1]: default scene %dx%d, %d spp per GPU as %d accumulated frames of 1 ray/pixel, maxBounces 3" % (W, H, spp, spp),
-                       "width": W, "height": H, "frames_per_gpu": spp, "total_spp": spp * world,
-                       "parallelism": "sample-split x%d (RCCL all-reduce of the accumulation image)" % world if distributed else "single GPU",
-                       "flavour": "fast" if args.fast else "strict"},
-            "ms_per_frame": ms_step / spp, "msamples_per_s": W * H * spp * world * args.steps / dt / 1e6,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": wl["data"],
+            "config": {"workload": wl["workload"] + (" (this run: %d frames per GPU)" % frames_rank if frames_rank != wl["frames"] else ""),
+                       "width": W, "height": H, "frames_per_gpu": frames_rank, "total_spp": spp_total,
+                       "parallelism": ("tile-split x%d, 64x64 tiles along a serpentine path, one all-gather of the owned tiles" % world if tile_split else
+                                       "sample-split x%d (one all-reduce of the accumulation image)" % world) +
+                                      (" inside librt_amd.so over RCCL" if native else " through torch.distributed/%s" % args.backend) if distributed else "single GPU",
+                       "flavour": "%s traversal, %s arithmetic" % (names[args.traversal], "FMA-contracted" if args.fast else "strict binary32"),
+                       "pipeline": pipeline},
+            "ms_per_frame": ms_step / frames_rank, "msamples_per_s": W * H * spp_total * args.steps / dt / 1e6,
             "rays_per_step": total_rays,
-            "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": {0: "rt_megakernel", 3: "rt_pairkernel"}.get(r.get_option(R.RT_OPT_PIPELINE), "pipeline %d" % r.get_option(R.RT_OPT_PIPELINE)), "launch_ms": launch_ms, "frames_per_launch": group,
-                         "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "valu": {"achieved_tflops": flops_per_launch / (launch_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
-                                  "frac": flops_per_launch / (launch_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},
+            "rays_counted": "exact (counting kernel over every frame of the step)" if len(counted) == len(my_frames) else
+                            "counting kernel over %d evenly spaced frames of %d, scaled" % (len(counted), len(my_frames)),
+            # The scene of configs 1 and 3 (1.2 MB) and of config 2 (15 MB) is served by the caches: the bound is
+            # vector-ALU issue and the latency of dependent record fetches, not HBM. `frac` is the achieved share of
+            # the FP32 vector peak in algorithmic flops (21 per box test, 45 per triangle test of the REFERENCE
+            # traversal); the algorithmic byte rate and the measured HBM traffic are given beside it.
+            "roofline": {"bound": "valu+latency" if cache_resident else "hbm",
+                         "achieved": alg_tflops if cache_resident else alg_gbps,
+                         "peak": VALU_PEAK_TFLOPS if cache_resident else HBM_PEAK_GBPS,
+                         "unit": "TFLOP/s" if cache_resident else "GB/s",
+                         "frac": alg_tflops / VALU_PEAK_TFLOPS if cache_resident else alg_gbps / HBM_PEAK_GBPS,
+                         "traffic": traffic,
+                         "traffic_gbps": None if traffic is None else traffic / (launch_ms * 1e-3) / 1e9,
+                         "kernel": kernel, "launch_ms": launch_ms, "frames_per_launch": group, "launches_per_step": launches,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_flops_per_launch": flops_per_launch,
+                         "scene_bytes": scene_bytes,
+                         "hbm": {"achieved_gbps_algorithmic": alg_gbps, "peak_gbps": HBM_PEAK_GBPS, "frac_algorithmic": alg_gbps / HBM_PEAK_GBPS,
+                                 "note": "algorithmic bytes (40 per box test, 48 per triangle test, 48 per pixel and frame) per second; "
+                                         "a work rate, not bytes that cross the HBM interface"},
+                         "valu": {"achieved_tflops": alg_tflops, "peak_tflops": VALU_PEAK_TFLOPS, "frac": alg_tflops / VALU_PEAK_TFLOPS}},
         }
+        if other is not None:
+            odt, okms = other
+            out["other_flavour"] = {"flavour": "%s traversal, %s arithmetic" % (names[1 - args.traversal], "FMA-contracted" if args.fast else "strict binary32"),
+                                    "value": total_rays * args.steps / odt / 1e6, "unit": "Mrays/s", "ms_per_step": odt / args.steps * 1e3,
+                                    "ms_per_frame": odt / args.steps * 1e3 / frames_rank, "launch_ms": okms / launches}
         if world == 1 and args.single_dispatch:
-            # the other reading of "64 spp": ONE dispatch with raysPerPixel = 64 (samples seeded by the
+            # the other reading of "64 spp": ONE dispatch with raysPerPixel = frames (samples seeded by the
             # sample index instead of the frame index, raytrace.comp:779-783), after the timed region
-            p64 = pc.copy()
-            p64.raysPerPixel = spp
-            p64.frame = 0
+            pN = pc.copy()
+            pN.raysPerPixel = frames_rank
+            pN.frame = 0
             target.clear()
-            r.render_frames(p64, 0, 1, 1)
+            r.render_frames(pN, 0, 1, 1)
             r.sync()
-            r.render_frames(p64, 0, 1, 1)
+            r.render_frames(pN, 0, 1, 1)
             r.sync()
-            out["ms_single_dispatch_%dspp" % spp] = r.last_render_ms()[0]
+            out["ms_single_dispatch_%dspp" % frames_rank] = r.last_render_ms()[0]
         if world == 1 and args.cpu_seconds > 0:
-            threads = min(16, os.cpu_count() or 1)
+            host_cpus = os.cpu_count() or 1
+            share = int(os.environ.get("OMP_NUM_THREADS", "16") or 16)      # the box sets it to a one-GPU job's CPU share
+            threads = max(1, min(host_cpus, share))
             p0 = pc.copy()
             p0.frame = 0
-            out["cpu_baseline"] = cpu_baseline(arrays, p0.as_bytes, W, H, args.cpu_seconds, threads)
+            dog.arm(args.stage_timeout + args.cpu_seconds * 4, "CPU baseline")
+            out["cpu_baseline"] = cpu_baseline(arrays, p0.as_bytes(), W, H, args.cpu_seconds, threads, host_cpus)
         print(json.dumps(out), flush=True)
+    dog.arm(args.stage_timeout, "shutdown")
     target.close()
     r.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    dog.disarm()
 
 
 if __name__ == "__main__":

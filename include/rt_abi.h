@@ -37,7 +37,8 @@ typedef enum rt_status {
     RT_ERR_NO_IMAGES      = -5,
     RT_ERR_SCENE_INVALID  = -6,
     RT_ERR_IO             = -7,
-    RT_ERR_UNSUPPORTED    = -8
+    RT_ERR_UNSUPPORTED    = -8,
+    RT_ERR_NOMEM          = -9      /* host memory exhausted (std::bad_alloc caught at the boundary) */
 } rt_status;
 
 enum { RT_IMAGE_DRAW = 0, RT_IMAGE_ACCUM = 1 };
@@ -56,7 +57,7 @@ enum {
      * results. 2 = wavefront: a ray that enters the box of a BVH parent is suspended (state in
      * HBM) and a second kernel, in which every lane takes the next ray as soon as its walk is
      * done, finishes its GetHit; further rounds of the path kernel pick the paths up again.
-     * Needs 176 bytes of device memory per pixel. Same arithmetic, same results. 3 = lock-step
+     * Needs about 430 bytes of device memory per pixel. Same arithmetic, same results. 3 = lock-step
      * with two samples per lane: when an rt_render_frames launch holds at least two samples of a
      * pixel (frames per launch x raysPerPixel), every lane traces two of them together and walks
      * its second ray while other lanes of the wave are still on their first, so the wave waits for

@@ -175,7 +175,7 @@ int launchTiles(rt_ctx* ctx, const TileGeometry& g, int firstRank, int ranks, in
 
 extern "C" {
 
-int rt_comm_unique_id(unsigned char id[RT_COMM_ID_BYTES])
+int rt_comm_unique_id(unsigned char id[RT_COMM_ID_BYTES]) try
 {
     if (!id) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "rt_comm_unique_id: null pointer");
     if (!loadRccl()) return rt_fail(nullptr, RT_ERR_UNSUPPORTED, g_rccl.error);
@@ -186,9 +186,9 @@ int rt_comm_unique_id(unsigned char id[RT_COMM_ID_BYTES])
     static_assert(sizeof(u) == RT_COMM_ID_BYTES, "id size");
     std::memcpy(id, &u, sizeof(u));
     return RT_OK;
-}
+} catch (...) { return rt_caught(nullptr); }
 
-int rt_comm_init(rt_ctx* ctx, const unsigned char id[RT_COMM_ID_BYTES], int rank, int world)
+int rt_comm_init(rt_ctx* ctx, const unsigned char id[RT_COMM_ID_BYTES], int rank, int world) try
 {
     if (!ctx || !id) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_comm_init: null argument");
     if (world < 1 || rank < 0 || rank >= world) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_comm_init: rank must be in [0, world)");
@@ -204,9 +204,9 @@ int rt_comm_init(rt_ctx* ctx, const unsigned char id[RT_COMM_ID_BYTES], int rank
     ctx->commRank = rank;
     ctx->commWorld = world;
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_comm_destroy(rt_ctx* ctx)
+int rt_comm_destroy(rt_ctx* ctx) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     (void)hipSetDevice(ctx->device);
@@ -219,17 +219,17 @@ int rt_comm_destroy(rt_ctx* ctx)
     ctx->dGather = nullptr;
     ctx->gatherBytes = 0;
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_comm_info(rt_ctx* ctx, int* rank, int* world)
+int rt_comm_info(rt_ctx* ctx, int* rank, int* world) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (rank) *rank = ctx->comm ? ctx->commRank : 0;
     if (world) *world = ctx->comm ? ctx->commWorld : 0;
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_merge_accum(rt_ctx* ctx)
+int rt_merge_accum(rt_ctx* ctx) try
 {
     int rc = checkImages(ctx, "rt_merge_accum");
     if (rc != RT_OK) return rc;
@@ -239,9 +239,9 @@ int rt_merge_accum(rt_ctx* ctx)
     const int r = g_rccl.allReduce(ctx->accum, ctx->accum, floats, kRcclFloat, kRcclSum, ctx->comm, ctx->stream);
     if (r != 0) return failRccl(ctx, r, "ncclAllReduce");
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_gather_tiles(rt_ctx* ctx)
+int rt_gather_tiles(rt_ctx* ctx) try
 {
     int rc = checkImages(ctx, "rt_gather_tiles");
     if (rc != RT_OK) return rc;
@@ -258,9 +258,9 @@ int rt_gather_tiles(rt_ctx* ctx)
     const int r = g_rccl.allGather(base + (size_t)ctx->commRank * sliceBytes, base, sliceBytes, kRcclChar, ctx->comm, ctx->stream);
     if (r != 0) return failRccl(ctx, r, "ncclAllGather");
     return launchTiles(ctx, g, 0, ctx->commWorld, ctx->commRank, 0);
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_merge_accum_local(rt_ctx** ctxs, int n)
+int rt_merge_accum_local(rt_ctx** ctxs, int n) try
 {
     if (!ctxs || n < 1) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "rt_merge_accum_local: need at least one context");
     for (int i = 0; i < n; ++i) {
@@ -297,9 +297,9 @@ int rt_merge_accum_local(rt_ctx** ctxs, int n)
     }
     (void)hipFree(staging);
     return rc;
-}
+} catch (...) { return rt_caught(nullptr); }
 
-int rt_gather_tiles_local(rt_ctx** ctxs, int n)
+int rt_gather_tiles_local(rt_ctx** ctxs, int n) try
 {
     if (!ctxs || n < 1) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "rt_gather_tiles_local: need at least one context");
     for (int i = 0; i < n; ++i) {
@@ -335,6 +335,6 @@ int rt_gather_tiles_local(rt_ctx** ctxs, int n)
         RT_HIP(c, hipStreamSynchronize(c->stream));
     }
     return RT_OK;
-}
+} catch (...) { return rt_caught(nullptr); }
 
 } // extern "C"

@@ -88,6 +88,8 @@ struct rt_ctx {
 int rt_fail(rt_ctx* ctx, int code, const std::string& msg);
 int rt_fail_hip(rt_ctx* ctx, hipError_t e, const char* what);
 const char* rt_global_error();
+// For `catch (...)` handlers of exported functions: classifies the exception in flight, records a message.
+int rt_caught(rt_ctx* ctx) noexcept;
 
 #define RT_HIP(ctx, call)                                         \
     do {                                                          \

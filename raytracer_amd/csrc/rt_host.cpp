@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
@@ -72,6 +73,20 @@ int rt_fail(rt_ctx* ctx, int code, const std::string& msg)
 int rt_fail_hip(rt_ctx* ctx, hipError_t e, const char* what)
 {
     return rt_fail(ctx, RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// Handler of every exported function's function-try-block: no C++ exception crosses the C ABI. The
+// messages are short enough for the string's in-place buffer, so recording them cannot throw again.
+int rt_caught(rt_ctx* ctx) noexcept
+{
+    int code = RT_ERR_INVALID_ARG;
+    const char* text = "internal error";
+    try { throw; }
+    catch (const std::bad_alloc&) { code = RT_ERR_NOMEM; text = "out of memory"; }
+    catch (const std::length_error&) { code = RT_ERR_NOMEM; text = "too large"; }
+    catch (...) { }
+    try { if (ctx) ctx->error.assign(text); g_rtError.assign(text); } catch (...) { }
+    return code;
 }
 
 const char* rt_global_error() { return g_rtError.c_str(); }
@@ -487,6 +502,9 @@ int checkRenderable(rt_ctx* ctx, const rt_push_constants* pc)
                                                  std::to_string(ctx->scene.objectCount) + " uploaded parent nodes");
     if (pc->renderMode == 0 || pc->renderMode == 3 || pc->renderMode == 4) {
         if (pc->raysPerPixel < 0) return rt_fail(ctx, RT_ERR_INVALID_ARG, "raysPerPixel is negative");
+        // a launch holds up to RT_OPT_FRAMES_PER_LAUNCH frames of raysPerPixel samples, counted in an int
+        if ((long long)pc->raysPerPixel * (long long)std::max(1, ctx->framesPerLaunch) > 0x7fffffffLL)
+            return rt_fail(ctx, RT_ERR_INVALID_ARG, "raysPerPixel x frames per launch exceeds 2^31 - 1");
     }
     return RT_OK;
 }
@@ -514,10 +532,13 @@ int ensureWavefront(rt_ctx* ctx, const DevLaunch& L, int parts)
     const size_t cus = (size_t)std::max(1, ctx->computeUnits);
     for (int k = 0; k < parts; ++k) {
         const DevLaunch P = partLaunch(L, k, parts);
-        // a round's list holds at most one entry per pixel of the partition, plus one partly used
-        // block of 256 entries per wave of the path kernel's grid
+        // Upper bound of a round's list. A path is one job at most, so a round has at most `pixels` live
+        // entries. A wave fills 256-entry blocks and closes a block when the (at most 64) entries of one
+        // append do not fit, leaving fewer than 64 of its 256 entries unused: live entries take at most
+        // 256/193 < 4/3 of their number in list space. At the end of the kernel every wave of the grid leaves
+        // one partly used block. Unused entries are skipped by the next round and do not carry over.
         const size_t pixels = (size_t)P.ownedTiles * (size_t)L.tileSize * (size_t)L.tileSize;
-        const size_t listCap = ((pixels + cus * (size_t)ctx->wavesPerCU * 256 + 63) / 64) * 64 + 64;
+        const size_t listCap = ((pixels + pixels / 3 + 64 + cus * (size_t)ctx->wavesPerCU * 256 + 63) / 64) * 64 + 64;
         if (listCap > 0x7fffffffULL) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "image too large for the wavefront pipeline");
         const size_t ctlBytes = 4096;
         static_assert((RT_WF_MAX_ROUNDS + 2) * RT_WF_WORDS_PER_ROUND * sizeof(uint32_t) <= 4096, "control block");
@@ -631,7 +652,7 @@ const char* rt_version(void) { return "rt_amd 0.1 (gfx950)"; }
 
 const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->error.c_str() : rt_global_error(); }
 
-int rt_create(int device_id, rt_ctx** out_ctx)
+int rt_create(int device_id, rt_ctx** out_ctx) try
 {
     if (!out_ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: null out pointer");
     *out_ctx = nullptr;
@@ -655,7 +676,7 @@ int rt_create(int device_id, rt_ctx** out_ctx)
     c->stream = c->ownStream;
     *out_ctx = c;
     return RT_OK;
-}
+} catch (...) { return rt_caught(nullptr); }
 
 void rt_destroy(rt_ctx* c)
 {
@@ -679,7 +700,7 @@ void rt_destroy(rt_ctx* c)
     delete c;
 }
 
-int rt_set_stream(rt_ctx* ctx, void* hip_stream)
+int rt_set_stream(rt_ctx* ctx, void* hip_stream) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -687,9 +708,9 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream)
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->ownStream;
     ctx->timed = false;
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_set_option(rt_ctx* ctx, int option, int value)
+int rt_set_option(rt_ctx* ctx, int option, int value) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     switch (option) {
@@ -754,9 +775,9 @@ int rt_set_option(rt_ctx* ctx, int option, int value)
         return RT_OK;
     default: return rt_fail(ctx, RT_ERR_INVALID_ARG, "unknown option");
     }
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_get_option(rt_ctx* ctx, int option, int* value)
+int rt_get_option(rt_ctx* ctx, int option, int* value) try
 {
     if (!ctx || !value) return rt_fail(ctx, RT_ERR_INVALID_ARG, "null argument");
     switch (option) {
@@ -787,9 +808,9 @@ int rt_get_option(rt_ctx* ctx, int option, int* value)
     case RT_OPT_TILE_SIZE: *value = ctx->tileSize; return RT_OK;
     default: return rt_fail(ctx, RT_ERR_INVALID_ARG, "unknown option");
     }
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b) try
 {
     if (!ctx || !b) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_scene: null argument");
     // shape checks that must hold before any array is indexed
@@ -874,9 +895,9 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b)
     ctx->hTris = std::move(rl.dTris);
     ctx->haveScene = true;
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_resize(rt_ctx* ctx, int width, int height)
+int rt_resize(rt_ctx* ctx, int width, int height) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (width <= 0 || height <= 0 || width > 65536 || height > 65536) return rt_fail(ctx, RT_ERR_INVALID_ARG, "image size out of range");
@@ -893,9 +914,9 @@ int rt_resize(rt_ctx* ctx, int width, int height)
     RT_HIP(ctx, hipMemsetAsync(ctx->draw, 0, bytes, ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(ctx->accum, 0, bytes, ctx->stream));
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_bind_images(rt_ctx* ctx, void* draw_dev, void* accum_dev, int width, int height)
+int rt_bind_images(rt_ctx* ctx, void* draw_dev, void* accum_dev, int width, int height) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -907,6 +928,7 @@ int rt_bind_images(rt_ctx* ctx, void* draw_dev, void* accum_dev, int width, int 
         return RT_OK;
     }
     if (!draw_dev || !accum_dev || width <= 0 || height <= 0) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_bind_images: need both images and a size");
+    if (width > 65536 || height > 65536) return rt_fail(ctx, RT_ERR_INVALID_ARG, "image size out of range");
     if (((uintptr_t)draw_dev & 15) || ((uintptr_t)accum_dev & 15)) return rt_fail(ctx, RT_ERR_INVALID_ARG, "images must be 16-byte aligned");
     freeImages(ctx);
     ctx->draw = draw_dev;
@@ -914,18 +936,18 @@ int rt_bind_images(rt_ctx* ctx, void* draw_dev, void* accum_dev, int width, int 
     ctx->width = width;
     ctx->height = height;
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_clear_accumulation(rt_ctx* ctx)
+int rt_clear_accumulation(rt_ctx* ctx) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (!ctx->accum) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipMemsetAsync(ctx->accum, 0, (size_t)ctx->width * ctx->height * 16, ctx->stream));
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, int stride, int count)
+int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, int stride, int count) try
 {
     int rc = checkRenderable(ctx, pc);
     if (rc != RT_OK) return rc;
@@ -946,23 +968,23 @@ int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, 
     ctx->timed = true;
     ctx->lastFrames = count;
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_render_frame(rt_ctx* ctx, const rt_push_constants* pc)
+int rt_render_frame(rt_ctx* ctx, const rt_push_constants* pc) try
 {
     if (!pc) return rt_fail(ctx, RT_ERR_INVALID_ARG, "null push constants");
     return rt_render_frames(ctx, pc, pc->frame, 1, 1);
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_sync(rt_ctx* ctx)
+int rt_sync(rt_ctx* ctx) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_read_image(rt_ctx* ctx, int which, float* dst, size_t bytes)
+int rt_read_image(rt_ctx* ctx, int which, float* dst, size_t bytes) try
 {
     if (!ctx || !dst) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_read_image: null argument");
     if (!ctx->draw || !ctx->accum) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images");
@@ -973,9 +995,9 @@ int rt_read_image(rt_ctx* ctx, int which, float* dst, size_t bytes)
     RT_HIP(ctx, hipMemcpyAsync(dst, which == RT_IMAGE_DRAW ? ctx->draw : ctx->accum, need, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_write_accum(rt_ctx* ctx, const float* src, size_t bytes)
+int rt_write_accum(rt_ctx* ctx, const float* src, size_t bytes) try
 {
     if (!ctx || !src) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_write_accum: null argument");
     if (!ctx->accum) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images");
@@ -985,9 +1007,9 @@ int rt_write_accum(rt_ctx* ctx, const float* src, size_t bytes)
     RT_HIP(ctx, hipMemcpyAsync(ctx->accum, src, need, hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_resolve(rt_ctx* ctx, int total_frames)
+int rt_resolve(rt_ctx* ctx, int total_frames) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (!ctx->draw || !ctx->accum) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images");
@@ -997,9 +1019,9 @@ int rt_resolve(rt_ctx* ctx, int total_frames)
     hipError_t e = fn(ctx->accum, ctx->draw, (size_t)ctx->width * ctx->height, 1.0f / (float)total_frames, ctx->stream);
     if (e != hipSuccess) return rt_fail_hip(ctx, e, "resolve launch");
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out)
+int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out) try
 {
     int rc = checkRenderable(ctx, pc);
     if (rc != RT_OK) return rc;
@@ -1015,9 +1037,9 @@ int rt_frame_stats_compute(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_st
     out->triangleTests = h.triTests;
     out->samples = h.samples;
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_frame_stats_noalloc(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out_dev)
+int rt_frame_stats_noalloc(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_stats* out_dev) try
 {
     int rc = checkRenderable(ctx, pc);
     if (rc != RT_OK) return rc;
@@ -1046,9 +1068,9 @@ int rt_frame_stats_noalloc(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_st
     if (e == hipSuccess) e = rt_noalloc_sum(slots, (int)waves, out_dev, ctx->stream);
     if (e != hipSuccess) return rt_fail_hip(ctx, e, "rt_frame_stats_noalloc launch");
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16])
+int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16]) try
 {
     int rc = checkRenderable(ctx, pc);
     if (rc != RT_OK) return rc;
@@ -1062,9 +1084,9 @@ int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16]
     RT_HIP(ctx, hipMemcpyAsync(out, d, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_frame)
+int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_frame) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (!ctx->timed) return rt_fail(ctx, RT_ERR_INVALID_ARG, "nothing has been rendered on this stream yet");
@@ -1075,17 +1097,17 @@ int rt_last_render_ms(rt_ctx* ctx, float* ms_total, float* ms_per_frame)
     if (ms_total) *ms_total = ms;
     if (ms_per_frame) *ms_per_frame = ctx->lastFrames > 0 ? ms / (float)ctx->lastFrames : 0.0f;
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_image_size(rt_ctx* ctx, int* width, int* height)
+int rt_image_size(rt_ctx* ctx, int* width, int* height) try
 {
     if (!ctx) return rt_fail(nullptr, RT_ERR_INVALID_ARG, "null context");
     if (width) *width = ctx->width;
     if (height) *height = ctx->height;
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_save_png(rt_ctx* ctx, const char* path)
+int rt_save_png(rt_ctx* ctx, const char* path) try
 {
     if (!ctx || !path) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_save_png: null argument");
     if (!ctx->draw) return rt_fail(ctx, RT_ERR_NO_IMAGES, "no images (call rt_resize or rt_bind_images first)");
@@ -1098,9 +1120,9 @@ int rt_save_png(rt_ctx* ctx, const char* path)
     rc = rt_write_png_rgba8(path, b.data(), ctx->width, ctx->height);
     if (rc != RT_OK) return rt_fail(ctx, rc, std::string("cannot write ") + path);
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_produce_render(rt_ctx* ctx, rt_push_constants* pc, int render_frames, const char* png_path, double* seconds)
+int rt_produce_render(rt_ctx* ctx, rt_push_constants* pc, int render_frames, const char* png_path, double* seconds) try
 {
     if (!ctx || !pc) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_produce_render: null argument");
     const auto t0 = std::chrono::system_clock::now();
@@ -1114,9 +1136,9 @@ int rt_produce_render(rt_ctx* ctx, rt_push_constants* pc, int render_frames, con
     if (rc != RT_OK) return rc;
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::system_clock::now() - t0).count();
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
-int rt_math_apply(rt_ctx* ctx, int which, const float* x, float* y, size_t n)
+int rt_math_apply(rt_ctx* ctx, int which, const float* x, float* y, size_t n) try
 {
     if (!ctx || (n && (!x || !y)) || which < 0 || which > 3) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_math_apply: bad argument");
     if (n == 0) return RT_OK;
@@ -1132,6 +1154,6 @@ int rt_math_apply(rt_ctx* ctx, int which, const float* x, float* y, size_t n)
     if (dy) (void)hipFree(dy);
     if (e != hipSuccess) return rt_fail_hip(ctx, e, "rt_math_apply");
     return RT_OK;
-}
+} catch (...) { return rt_caught(ctx); }
 
 } // extern "C"

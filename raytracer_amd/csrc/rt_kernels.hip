@@ -732,7 +732,6 @@ struct PathState {
     V3 throughput, result;
     V3 sun;               // sun term of the last hit, added when its shadow ray comes back unblocked
     V3 so;                // origin of that shadow ray
-    uint32_t seed;
     bool alive;           // wants a regular GetHit
     bool shadow;          // wants a shadow GetHit
 };
@@ -862,7 +861,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
 // The part of RayColour's loop body between two GetHit calls (raytrace.comp:701-766) for one path:
 // takes the regular hit, adds sky / emission, ends the path or prepares the shadow ray (sun term kept
 // aside until the shadow ray's answer is in) and the next regular ray.
-__device__ __forceinline__ void pair_shade(const DevScene& S, const rt_push_constants& pc, PathState& p, V3 dirN, const Best& best)
+__device__ __forceinline__ void pair_shade(const DevScene& S, const rt_push_constants& pc, PathState& p, V3 dirN, const Best& best, uint32_t seed)
 {
     p.shadow = false;
     if (!p.alive) return;
@@ -891,10 +890,17 @@ __device__ __forceinline__ void pair_shade(const DevScene& S, const rt_push_cons
     }
     V3 attenuation;
     Ray scattered;
-    material_scatter(m, p.d, rec, p.seed, attenuation, scattered);
+    material_scatter(m, p.d, rec, seed, attenuation, scattered);
     p.throughput = p.throughput * attenuation;
     p.o = scattered.o;
     p.d = scattered.d;
+}
+
+// SeedFromCoords of entry m of a pixel's sample sequence (frame m / rpp of the launch, sample m % rpp)
+__device__ __forceinline__ uint32_t pair_seed(const rt_push_constants& pc, const DevLaunch& L, int x, int y, int m, int rpp)
+{
+    const int fr = m / rpp, i = m - fr * rpp;
+    return seed_from_coords((uint32_t)x, (uint32_t)y, (uint32_t)(pc.frame + fr * L.frameStride), (uint32_t)i);
 }
 
 __device__ __forceinline__ float linear_to_gamma(float c) { return c > 0.0f ? sqrtf(c) : 0.0f; }
@@ -1046,7 +1052,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT
 // Pathtrace (raytrace.comp:771-817) with two samples per lane: the samples of a pixel - frames
 // pc.frame, pc.frame + L.frameStride, ... (L.frames of them), pc.raysPerPixel samples each - are taken
 // two at a time, traced together by trace_pair() and added to the pixel in sequence order.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT_SYM(rt_pairkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
+#ifndef RT_PAIR_WAVES
+#define RT_PAIR_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVES))) void RT_SYM(rt_pairkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
                                                             float4* __restrict__ accum, float4* __restrict__ out)
 {
     extern __shared__ uint2 stackMem[];
@@ -1086,9 +1095,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT
             p.result = mk(0.0f, 0.0f, 0.0f);
             p.sun = mk(0.0f, 0.0f, 0.0f);
             p.so = mk(0.0f, 0.0f, 0.0f);
-            const int fr = m / rpp, i = m - fr * rpp;
-            p.seed = seed_from_coords((uint32_t)x, (uint32_t)y, (uint32_t)(pc.frame + fr * L.frameStride), (uint32_t)i);
-            Ray ray = get_ray(pc, x, y, p.seed);
+            Ray ray = get_ray(pc, x, y, pair_seed(pc, L, x, y, m, rpp));
             p.o = ray.o; p.d = ray.d;
         }
         for (int bounce = 0; bounce < bounces; ++bounce) {
@@ -1096,8 +1103,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT
             const V3 dirA = normalize3(P[0].d), dirB = normalize3(P[1].d);
             Best bA, bB;
             trace_pair<false>(S, pc.parentBVHCount, P[0].o, dirA, P[0].alive, bA, P[1].o, dirB, P[1].alive, bB, 0.001f, 1e20f, stack);
-            pair_shade(S, pc, P[0], dirA, bA);
-            pair_shade(S, pc, P[1], dirB, bB);
+            // (the seed of a sample is recomputed where it is needed rather than carried through the walks)
+            pair_shade(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, y, n, rpp));
+            pair_shade(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, y, n + 1, rpp));
             if (P[0].shadow || P[1].shadow) {
                 trace_pair<true>(S, pc.parentBVHCount, P[0].so, sunDirN, P[0].shadow, bA, P[1].so, sunDirN, P[1].shadow, bB, 0.001f, 1e20f, stack);
                 if (P[0].shadow && bA.object < 0) P[0].result = P[0].result + P[0].sun;

@@ -22,6 +22,8 @@
 #include <fstream>
 #include <memory>
 #include <sstream>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -486,6 +488,19 @@ int fail(rt_scene* s, int code, const std::string& msg)
     return code;
 }
 
+// Handler of the exported functions' function-try-blocks: no C++ exception crosses the C ABI.
+int scene_caught(rt_scene* s) noexcept
+{
+    int code = RT_ERR_INVALID_ARG;
+    const char* text = "internal error";
+    try { throw; }
+    catch (const std::bad_alloc&) { code = RT_ERR_NOMEM; text = "out of memory"; }
+    catch (const std::length_error&) { code = RT_ERR_NOMEM; text = "too large"; }
+    catch (...) { }
+    try { if (s) s->error.assign(text); g_sceneError.assign(text); } catch (...) { }
+    return code;
+}
+
 int nodeDepth(const rt_scene& s, int node, int& maxLeaf, int guard)
 {
     if (guard > 4096) return guard;
@@ -534,30 +549,30 @@ void rt_default_camera(rt_camera_settings* cam)
     cam->defocusAngle = 0.0f;
 }
 
-int rt_scene_add_material(rt_scene* s, const rt_gpu_material* m)
+int rt_scene_add_material(rt_scene* s, const rt_gpu_material* m) try
 {
     if (!s || !m) return fail(s, RT_ERR_INVALID_ARG, "rt_scene_add_material: null argument");
     s->materials.push_back(*m);
     return (int)s->materials.size() - 1;
-}
+} catch (...) { return scene_caught(s); }
 
-int rt_scene_material_index(rt_scene* s, const rt_gpu_material* m)
+int rt_scene_material_index(rt_scene* s, const rt_gpu_material* m) try
 {
     if (!s || !m) return -1;
     for (size_t i = 0; i < s->materials.size(); ++i)
         if (sameMaterial(s->materials[i], *m)) return (int)i;
     return -1;
-}
+} catch (...) { return scene_caught(s); }
 
-int rt_scene_set_material(rt_scene* s, int index, const rt_gpu_material* m)
+int rt_scene_set_material(rt_scene* s, int index, const rt_gpu_material* m) try
 {
     if (!s || !m || index < 0 || (size_t)index >= s->materials.size())
         return fail(s, RT_ERR_INVALID_ARG, "rt_scene_set_material: bad index");
     s->materials[index] = *m;
     return RT_OK;
-}
+} catch (...) { return scene_caught(s); }
 
-int rt_scene_load_model(rt_scene* s, const char* obj_path)
+int rt_scene_load_model(rt_scene* s, const char* obj_path) try
 {
     if (!s || !obj_path) return fail(s, RT_ERR_INVALID_ARG, "rt_scene_load_model: null argument");
     const std::string path(obj_path);
@@ -643,10 +658,10 @@ int rt_scene_load_model(rt_scene* s, const char* obj_path)
     model.nodeCount = (int)nodes.size();
     s->models[path] = model;
     return RT_OK;
-}
+} catch (...) { return scene_caught(s); }
 
 int rt_scene_add_object(rt_scene* s, const char* model_path, const float position[3], const float rotation_deg[3],
-                        const float scale_[3], const rt_gpu_material* material)
+                        const float scale_[3], const rt_gpu_material* material) try
 {
     if (!s || !model_path || !position || !rotation_deg || !scale_)
         return fail(s, RT_ERR_INVALID_ARG, "rt_scene_add_object: null argument");
@@ -658,10 +673,10 @@ int rt_scene_add_object(rt_scene* s, const char* model_path, const float positio
     o.materialIndex = material ? rt_scene_material_index(s, material) : -1;
     s->objects.push_back(o);
     return (int)s->objects.size() - 1;
-}
+} catch (...) { return scene_caught(s); }
 
 int rt_scene_set_object(rt_scene* s, int index, const float position[3], const float rotation_deg[3],
-                        const float scale_[3], int material_index)
+                        const float scale_[3], int material_index) try
 {
     if (!s || index < 0 || (size_t)index >= s->objects.size())
         return fail(s, RT_ERR_INVALID_ARG, "rt_scene_set_object: bad index");
@@ -671,13 +686,13 @@ int rt_scene_set_object(rt_scene* s, int index, const float position[3], const f
     if (scale_) o.scale = { scale_[0], scale_[1], scale_[2] };
     o.materialIndex = material_index;
     return RT_OK;
-}
+} catch (...) { return scene_caught(s); }
 
 int rt_scene_object_count(rt_scene* s) { return s ? (int)s->objects.size() : 0; }
 int rt_scene_material_count(rt_scene* s) { return s ? (int)s->materials.size() : 0; }
 
 int rt_scene_get_object(rt_scene* s, int index, char* model_path, size_t model_path_cap, float position[3],
-                        float rotation_deg[3], float scale_[3], int* material_index)
+                        float rotation_deg[3], float scale_[3], int* material_index) try
 {
     if (!s || index < 0 || (size_t)index >= s->objects.size())
         return fail(s, RT_ERR_INVALID_ARG, "rt_scene_get_object: bad index");
@@ -692,17 +707,17 @@ int rt_scene_get_object(rt_scene* s, int index, char* model_path, size_t model_p
     if (scale_) { scale_[0] = o.scale.x; scale_[1] = o.scale.y; scale_[2] = o.scale.z; }
     if (material_index) *material_index = o.materialIndex;
     return RT_OK;
-}
+} catch (...) { return scene_caught(s); }
 
-int rt_scene_get_material(rt_scene* s, int index, rt_gpu_material* out)
+int rt_scene_get_material(rt_scene* s, int index, rt_gpu_material* out) try
 {
     if (!s || !out || index < 0 || (size_t)index >= s->materials.size())
         return fail(s, RT_ERR_INVALID_ARG, "rt_scene_get_material: bad index");
     *out = s->materials[index];
     return RT_OK;
-}
+} catch (...) { return scene_caught(s); }
 
-int rt_scene_buffer_data(rt_scene* s)
+int rt_scene_buffer_data(rt_scene* s) try
 {
     if (!s) return fail(s, RT_ERR_INVALID_ARG, "rt_scene_buffer_data: null scene");
     s->gpuObjects.clear();
@@ -748,9 +763,9 @@ int rt_scene_buffer_data(rt_scene* s)
         s->parentBVH.push_back(p);
     }
     return RT_OK;
-}
+} catch (...) { return scene_caught(s); }
 
-int rt_scene_get_buffers(rt_scene* s, rt_scene_buffers* out)
+int rt_scene_get_buffers(rt_scene* s, rt_scene_buffers* out) try
 {
     if (!s || !out) return fail(s, RT_ERR_INVALID_ARG, "rt_scene_get_buffers: null argument");
     auto view = [](const auto& v) { return rt_buffer_view{ v.empty() ? nullptr : (const void*)v.data(), v.size() }; };
@@ -764,9 +779,9 @@ int rt_scene_get_buffers(rt_scene* s, rt_scene_buffers* out)
     out->bvhNodeLeftChildren = view(s->left); out->bvhNodeRightChildren = view(s->right);
     out->bvhNodeTriangleStartIndices = view(s->triStart); out->bvhNodeTriangleCounts = view(s->triCount);
     return RT_OK;
-}
+} catch (...) { return scene_caught(s); }
 
-int rt_scene_model_info(rt_scene* s, const char* model_path, int* triangles, int* nodes, int* max_depth, int* max_leaf)
+int rt_scene_model_info(rt_scene* s, const char* model_path, int* triangles, int* nodes, int* max_depth, int* max_leaf) try
 {
     if (!s || !model_path) return fail(s, RT_ERR_INVALID_ARG, "rt_scene_model_info: null argument");
     auto it = s->models.find(model_path);
@@ -783,9 +798,9 @@ int rt_scene_model_info(rt_scene* s, const char* model_path, int* triangles, int
     if (max_depth) *max_depth = depth;
     if (max_leaf) *max_leaf = leaf;
     return RT_OK;
-}
+} catch (...) { return scene_caught(s); }
 
-int rt_scene_init_default(rt_scene* s, const char* models_dir, const char* dragon_file)
+int rt_scene_init_default(rt_scene* s, const char* models_dir, const char* dragon_file) try
 {
     if (!s || !models_dir) return fail(s, RT_ERR_INVALID_ARG, "rt_scene_init_default: null argument");
     auto material = [](float r, float g, float b) {
@@ -826,9 +841,9 @@ int rt_scene_init_default(rt_scene* s, const char* models_dir, const char* drago
     };
     for (const Placement& pl : placements) rt_scene_add_object(s, pl.model->c_str(), pl.p, pl.r, pl.sc, pl.mat);
     return rt_scene_buffer_data(s);
-}
+} catch (...) { return scene_caught(s); }
 
-int rt_camera_to_push_constants(const rt_camera_settings* cam, int width, int height, rt_push_constants* pc)
+int rt_camera_to_push_constants(const rt_camera_settings* cam, int width, int height, rt_push_constants* pc) try
 {
     if (!cam || !pc || width <= 0 || height <= 0) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_camera_to_push_constants: bad argument");
     const float theta = radiansf(cam->cameraFov);
@@ -861,7 +876,7 @@ int rt_camera_to_push_constants(const rt_camera_settings* cam, int width, int he
     put(pc->defocusDiskU, Vec3{ dr * u.x, dr * u.y, dr * u.z });
     put(pc->defocusDiskV, Vec3{ dr * v.x, dr * v.y, dr * v.z });
     return RT_OK;
-}
+} catch (...) { return scene_caught(nullptr); }
 
 void rt_rgba32f_to_rgba8(const float* src, uint8_t* dst, size_t pixel_count)
 {
@@ -879,7 +894,7 @@ void rt_rgba32f_to_rgba8(const float* src, uint8_t* dst, size_t pixel_count)
 // (HardwareRenderer.cpp:1127-1134). The pixel rows go into stored (uncompressed) deflate blocks with
 // filter type 0, so every decoder returns exactly the bytes passed in; only the file size differs
 // from what a compressing writer produces.
-int rt_write_png_rgba8(const char* path, const uint8_t* rgba, int width, int height)
+int rt_write_png_rgba8(const char* path, const uint8_t* rgba, int width, int height) try
 {
     if (!path || !rgba || width <= 0 || height <= 0) return RT_ERR_INVALID_ARG;
     static uint32_t crcTable[256];
@@ -943,6 +958,6 @@ int rt_write_png_rgba8(const char* path, const uint8_t* rgba, int width, int hei
     if (!f) return RT_ERR_IO;
     const bool ok = std::fwrite(file.data(), 1, file.size(), f) == file.size();
     return (std::fclose(f) == 0 && ok) ? RT_OK : RT_ERR_IO;
-}
+} catch (...) { return scene_caught(nullptr); }
 
 } // extern "C"
