@@ -1,7 +1,7 @@
 // viewer_loop.cpp - drives rtamd::HardwareRenderer (include/rt_renderer.hpp) the way the reference's
 // MainLoop drives its renderer (HardwareRenderer.cpp:973-1011), with a scripted input sequence in
 // place of the SDL event loop: idle frames, mouse lock, W / D movement, a mouse turn, a window
-// resize, a scene edit (SceneEditorUI's pattern: edit the lists, RebufferSceneData,
+// resize, a scene edit (SceneEditorUI's pattern: edit the lists - change, remove, append -, RebufferSceneData,
 // SetRefreshAccumulation) and an offline render request (SetRenderFrames + SetDoRender).
 //
 //   viewer_loop <models_dir> <out.png>      full session on HIP device 0
@@ -68,6 +68,15 @@ int main(int argc, char** argv)
 
             r.m_sceneMaterials[1].albedo[0] = 0.9f; r.m_sceneMaterials[1].albedo[1] = 0.2f; r.m_sceneMaterials[1].albedo[2] = 0.2f;
             r.m_sceneObjects[6].position.y += 0.5f;
+            // the lists are the front end's own: remove the last wall, append a material and a cube that uses it
+            r.m_sceneObjects.erase(r.m_sceneObjects.begin() + 7);
+            rtamd::GPUMaterial blue;
+            rt_default_material(&blue);
+            blue.albedo[0] = 0.2f; blue.albedo[1] = 0.3f; blue.albedo[2] = 0.9f;
+            r.m_sceneMaterials.push_back(blue);
+            const std::string cube = std::string(argv[1]) + "/cube.obj";
+            r.LoadModel(cube);
+            r.AddSceneObject(cube, rtamd::Vec3(3.0f, 1.0f, 2.0f), rtamd::Vec3(0.0f, 30.0f, 0.0f), rtamd::Vec3(1.0f, 1.0f, 1.0f), blue);
             r.RebufferSceneData();
             r.SetRefreshAccumulation();
             r.SetRenderFrames(8);

@@ -282,6 +282,11 @@ int rt_scene_add_object(rt_scene* s, const char* model_path, const float positio
 int rt_scene_set_object(rt_scene* s, int index, const float position[3],
                         const float rotation_deg[3], const float scale[3], int material_index);
 int rt_scene_set_material(rt_scene* s, int index, const rt_gpu_material* m);
+/* Empty the object list / the material list (the loaded models stay cached), so that a front end
+ * whose own lists shrank can hand them over again from scratch: the list half of ClearSceneData
+ * (HardwareRenderer.cpp:773-785), which RebufferSceneData runs before every BufferSceneData. */
+int rt_scene_clear_objects(rt_scene* s);
+int rt_scene_clear_materials(rt_scene* s);
 /* What the scene editor reads back (SceneEditorUI.hpp:23-97 walks m_sceneObjects and
  * m_sceneMaterials): the number of objects / materials and one entry of either list. model_path
  * may be NULL; otherwise it receives the object's model path (model_path_cap bytes available). */

@@ -201,29 +201,26 @@ public:
             o.rotation = Vec3(r[0], r[1], r[2]);
             o.scale = Vec3(s[0], s[1], s[2]);
         }
-        m_syncedObjects = m_sceneObjects.size();
-        m_syncedMaterials = m_sceneMaterials.size();
     }
 
     // BufferSceneData (HardwareRenderer.cpp:651-771): objects -> GPU objects and parent boxes on the
-    // host, then all 18 arrays to the device. The editable lists are the truth: entries the scene
-    // already holds are overwritten with their current values, new ones are appended.
+    // host, then all 18 arrays to the device. The editable lists are the truth, whatever was done to
+    // them (entries edited, appended, removed, reordered): as RebufferSceneData does in the reference
+    // (ClearSceneData, then BufferSceneData over the member vectors), the scene's lists are emptied and
+    // filled again from them; the loaded models stay cached.
     void BufferSceneData()
     {
-        for (size_t i = 0; i < m_sceneMaterials.size(); ++i) {
-            if (i < m_syncedMaterials) checkScene(rt_scene_set_material(m_scene, (int)i, &m_sceneMaterials[i]));
-            else checkScene(rt_scene_add_material(m_scene, &m_sceneMaterials[i]));
-        }
-        m_syncedMaterials = m_sceneMaterials.size();
+        checkScene(rt_scene_clear_materials(m_scene));
+        for (const GPUMaterial& m : m_sceneMaterials) checkScene(rt_scene_add_material(m_scene, &m));
+        checkScene(rt_scene_clear_objects(m_scene));
         for (size_t i = 0; i < m_sceneObjects.size(); ++i) {
             const SceneObject& o = m_sceneObjects[i];
             const float p[3] = { o.position.x, o.position.y, o.position.z };
             const float r[3] = { o.rotation.x, o.rotation.y, o.rotation.z };
             const float s[3] = { o.scale.x, o.scale.y, o.scale.z };
-            if (i >= m_syncedObjects) checkScene(rt_scene_add_object(m_scene, o.modelName.c_str(), p, r, s, nullptr));
+            checkScene(rt_scene_add_object(m_scene, o.modelName.c_str(), p, r, s, nullptr));
             checkScene(rt_scene_set_object(m_scene, (int)i, p, r, s, o.materialIndex));
         }
-        m_syncedObjects = m_sceneObjects.size();
         checkScene(rt_scene_buffer_data(m_scene));
         rt_scene_buffers buffers;
         checkScene(rt_scene_get_buffers(m_scene, &buffers));
@@ -334,50 +331,52 @@ private:
     rt_scene* m_scene = nullptr;
     bool m_bInitialized = false;
     int m_width = 0, m_height = 0, m_parentCount = 0;
-    size_t m_syncedObjects = 0, m_syncedMaterials = 0;
     double m_lastRenderSeconds = 0.0;
     std::vector<float> m_hostImage;
 };
 
-// CameraController::Update, CameraController.cpp:11-66
+// CameraController::Update (CameraController.cpp:11-66). The six movement keys are one table of
+// (held?, direction, sign); each held key displaces the camera by speed * direction * dt, applied key by
+// key in the reference's order W, S, A, D, Space, X (binary32, so the order is part of the result).
 inline void CameraController::Update(HardwareRenderer* renderer, const FrameInput& in)
 {
-    const float deltaTime = (float)in.deltaT;
     UpdateCameraRotation(renderer, in);
-
     if (in.escapePressed) m_bLockedMouse = !m_bLockedMouse;
     if (!m_bLockedMouse) return;
 
     CameraSettings& cam = renderer->m_camera;
-    bool hasMoved = false;
-    if (in.keyW) { cam.cameraPosition += m_fMoveSpeed * cam.cameraLookDirection * deltaTime; hasMoved = true; }
-    if (in.keyS) { cam.cameraPosition -= m_fMoveSpeed * cam.cameraLookDirection * deltaTime; hasMoved = true; }
-    if (in.keyA) { cam.cameraPosition -= m_fMoveSpeed * cross(cam.cameraLookDirection, Vec3(0, 1, 0)) * deltaTime; hasMoved = true; }
-    if (in.keyD) { cam.cameraPosition += m_fMoveSpeed * cross(cam.cameraLookDirection, Vec3(0, 1, 0)) * deltaTime; hasMoved = true; }
-    if (in.keySpace) { cam.cameraPosition += m_fMoveSpeed * Vec3(0, 1, 0) * deltaTime; hasMoved = true; }
-    if (in.keyX) { cam.cameraPosition -= m_fMoveSpeed * Vec3(0, 1, 0) * deltaTime; hasMoved = true; }
-    if (hasMoved) renderer->m_bRefreshAccumulation = true;
+    const float dt = (float)in.deltaT;
+    const Vec3 up(0, 1, 0);
+    const Vec3 ahead = cam.cameraLookDirection, sideways = cross(cam.cameraLookDirection, up);
+    const struct { bool held; Vec3 direction; bool forward; } keys[6] = {
+        { in.keyW, ahead, true }, { in.keyS, ahead, false }, { in.keyA, sideways, false },
+        { in.keyD, sideways, true }, { in.keySpace, up, true }, { in.keyX, up, false } };
+    int pressed = 0;
+    for (const auto& k : keys) {
+        if (!k.held) continue;
+        const Vec3 displacement = m_fMoveSpeed * k.direction * dt;
+        if (k.forward) cam.cameraPosition += displacement; else cam.cameraPosition -= displacement;
+        ++pressed;
+    }
+    if (pressed > 0) renderer->m_bRefreshAccumulation = true;
 }
 
-// CameraController::UpdateCameraRotation, CameraController.cpp:68-101
+// CameraController::UpdateCameraRotation (CameraController.cpp:68-101): yaw / pitch from the mouse
+// deltas scaled by sensitivity * dt, pitch kept within +-89 degrees, look direction from the two
+// angles; a changed direction asks for a fresh accumulation. While the mouse is free nothing turns
+// and the next locked frame counts as the first.
 inline void CameraController::UpdateCameraRotation(HardwareRenderer* renderer, const FrameInput& in)
 {
-    const float deltaTime = (float)in.deltaT;
-    const Vec3 oldDirection = renderer->m_camera.cameraLookDirection;
-    if (!m_bLockedMouse) {
-        m_bFirstMouse = true;
-        return;
-    }
-    const float effectiveSensitivity = m_fSensitivity * deltaTime;
-    yaw += in.mouseDeltaX * effectiveSensitivity;
-    pitch += -in.mouseDeltaY * effectiveSensitivity;
-    pitch = pitch < -89.0f ? -89.0f : (pitch > 89.0f ? 89.0f : pitch);
-    Vec3 front;
-    front.x = std::cos(radians(yaw)) * std::cos(radians(pitch));
-    front.y = std::sin(radians(pitch));
-    front.z = std::sin(radians(yaw)) * std::cos(radians(pitch));
-    renderer->m_camera.cameraLookDirection = normalize(front);
-    if (oldDirection != renderer->m_camera.cameraLookDirection) renderer->m_bRefreshAccumulation = true;
+    if (!m_bLockedMouse) { m_bFirstMouse = true; return; }
+    Vec3& look = renderer->m_camera.cameraLookDirection;
+    const Vec3 before = look;
+    const float scale = m_fSensitivity * (float)in.deltaT;
+    yaw += in.mouseDeltaX * scale;
+    pitch += -in.mouseDeltaY * scale;
+    pitch = std::fmin(std::fmax(pitch, -89.0f), 89.0f);
+    const float cp = std::cos(radians(pitch));
+    look = normalize(Vec3(std::cos(radians(yaw)) * cp, std::sin(radians(pitch)), std::sin(radians(yaw)) * cp));
+    if (before != look) renderer->m_bRefreshAccumulation = true;
 }
 
 } // namespace rtamd

@@ -835,7 +835,21 @@ static void ipush(ivec* v, int32_t x)
     v->d[v->n++] = x;
 }
 
-/* tiny_obj_loader.h:891-1021 (tryParseDouble) */
+/* tiny_obj_loader.h:891-1021 (tryParseDouble).
+ * The OBJ number parser and the face triangulation below follow tinyobjloader v2.0.0 statement by
+ * statement (the byte-exact vertex stream depends on it), which is
+ *   Copyright (c) 2012-Present, Syoyo Fujita and many contributors, released under the MIT License:
+ *   "Permission is hereby granted, free of charge, to any person obtaining a copy of this software and
+ *   associated documentation files (the "Software"), to deal in the Software without restriction,
+ *   including without limitation the rights to use, copy, modify, merge, publish, distribute,
+ *   sublicense, and/or sell copies of the Software, and to permit persons to whom the Software is
+ *   furnished to do so, subject to the following conditions: The above copyright notice and this
+ *   permission notice shall be included in all copies or substantial portions of the Software.
+ *   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT
+ *   NOT LIMITED TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND
+ *   NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES
+ *   OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN
+ *   CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE." */
 static int obj_parse_double(const char* s, const char* s_end, double* result)
 {
     if (s >= s_end) return 0;

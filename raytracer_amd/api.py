@@ -149,6 +149,7 @@ def load_library():
         "rt_scene_load_model": (ci, [vp, C.c_char_p]),
         "rt_scene_add_object": (ci, [vp, C.c_char_p, P(cf), P(cf), P(cf), P(Material)]),
         "rt_scene_set_object": (ci, [vp, ci, P(cf), P(cf), P(cf), ci]), "rt_scene_set_material": (ci, [vp, ci, P(Material)]),
+        "rt_scene_clear_objects": (ci, [vp]), "rt_scene_clear_materials": (ci, [vp]),
         "rt_scene_object_count": (ci, [vp]), "rt_scene_material_count": (ci, [vp]),
         "rt_scene_get_object": (ci, [vp, ci, C.c_char_p, C.c_size_t, P(cf), P(cf), P(cf), P(ci)]),
         "rt_scene_get_material": (ci, [vp, ci, P(Material)]),
@@ -178,7 +179,7 @@ EXPORTED_SYMBOLS = [
     "rt_scene_get_buffers", "rt_scene_init_default", "rt_scene_model_info", "rt_rgba32f_to_rgba8", "rt_write_png_rgba8",
     "rt_save_png", "rt_produce_render", "rt_math_apply", "rt_scene_object_count", "rt_scene_material_count",
     "rt_scene_get_object", "rt_scene_get_material", "rt_frame_stats_noalloc", "rt_comm_unique_id", "rt_comm_init",
-    "rt_comm_destroy", "rt_comm_info", "rt_merge_accum", "rt_gather_tiles", "rt_merge_accum_local", "rt_gather_tiles_local"]
+    "rt_comm_destroy", "rt_comm_info", "rt_scene_clear_objects", "rt_scene_clear_materials", "rt_merge_accum", "rt_gather_tiles", "rt_merge_accum_local", "rt_gather_tiles_local"]
 
 
 def _f3(v):
@@ -297,6 +298,12 @@ class Scene:
 
     def set_object(self, index, position, rotation, scale, material_index):
         self._check(self.lib.rt_scene_set_object(self.h, index, _f3(position), _f3(rotation), _f3(scale), material_index))
+
+    def clear_objects(self):
+        self._check(self.lib.rt_scene_clear_objects(self.h))
+
+    def clear_materials(self):
+        self._check(self.lib.rt_scene_clear_materials(self.h))
 
     def object_count(self):
         return self.lib.rt_scene_object_count(self.h)

@@ -688,6 +688,21 @@ int rt_scene_set_object(rt_scene* s, int index, const float position[3], const f
     return RT_OK;
 } catch (...) { return scene_caught(s); }
 
+// The list half of ClearSceneData (HardwareRenderer.cpp:773-785): the loaded models stay cached.
+int rt_scene_clear_objects(rt_scene* s)
+{
+    if (!s) return fail(s, RT_ERR_INVALID_ARG, "rt_scene_clear_objects: null scene");
+    s->objects.clear();
+    return RT_OK;
+}
+
+int rt_scene_clear_materials(rt_scene* s)
+{
+    if (!s) return fail(s, RT_ERR_INVALID_ARG, "rt_scene_clear_materials: null scene");
+    s->materials.clear();
+    return RT_OK;
+}
+
 int rt_scene_object_count(rt_scene* s) { return s ? (int)s->objects.size() : 0; }
 int rt_scene_material_count(rt_scene* s) { return s ? (int)s->materials.size() : 0; }
 

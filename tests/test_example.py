@@ -81,11 +81,14 @@ def test_camera_controller_known_answers():
 
 
 @pytest.mark.gpu
-def test_viewer_loop_session_matches_the_python_binding(tmp_path):
+def test_viewer_loop_session_matches_the_oracle(tmp_path):
     """The frame counter follows MainLoop / RefreshAccumulation / ProduceRender (HardwareRenderer.cpp:840-848, 921-922,
-    1002-1005, 1039-1043), and the PNG the session writes equals what the Python binding renders for the same camera,
-    size and edited scene."""
+    1002-1005, 1039-1043), and the PNG the session writes equals the CPU oracle's render of the final camera and of
+    the edited scene (one material changed, one object moved, one object removed, one material and one object
+    appended), converted with the reference's float -> 8-bit rule."""
     from test_host import decode_png
+    import oracle_lib as O
+    import scenes
     import raytracer_amd as R
     png = str(tmp_path / "session.png")
     r = subprocess.run([VIEWER, MODELS, png], capture_output=True, text=True, timeout=300)
@@ -95,25 +98,28 @@ def test_viewer_loop_session_matches_the_python_binding(tmp_path):
     # step); the render request runs the counter up to SetRenderFrames' 8
     assert [s[k]["frame"] for k in range(1, 12)] == [1, 2, 3, 4, 1, 1, 1, 1, 2, 3, 8]
     assert all(s[k]["refresh"] == 0 for k in range(1, 12))
-    assert "size 256 144 objects 8 materials 9" in r.stdout and "Render took" in r.stdout
+    assert "size 256 144 objects 8 materials 10" in r.stdout and "Render took" in r.stdout
     W, H = 256, 144
+    # the edited scene, rebuilt for the oracle from the default scene's lists
     sc = R.Scene(); sc.init_default()
-    m = sc.get_material(1); m.albedo = (C_float3)(0.9, 0.2, 0.2); sc.set_material(1, m)
-    o = sc.get_object(6)
-    p = np.array(o["position"], np.float32); p[1] += np.float32(0.5)
-    sc.set_object(6, tuple(p), o["rotation"], o["scale"], o["material_index"])
-    sc.buffer_scene_data()
-    cam = R.default_camera()
-    cam.cameraPosition = (C_float3)(*s[11]["pos"]); cam.cameraLookDirection = (C_float3)(*s[11]["dir"])
-    rd = R.Renderer(0)
-    try:
-        rd.upload_scene(sc.buffers()); rd.resize(W, H)
-        pc = R.default_push_constants(); R.camera_to_push_constants(cam, W, H, pc); pc.parentBVHCount = 8
-        rd.render_frames(pc, 0, 1, 8)
-        img = rd.read_image(R.RT_IMAGE_DRAW)
-    finally:
-        rd.close()
-    assert np.array_equal(decode_png(png), R.rgba32f_to_rgba8(img))
+    mats = [np.frombuffer(bytes(sc.get_material(i)), np.float32).copy() for i in range(sc.material_count())]
+    mats[1][0:3] = (0.9, 0.2, 0.2)
+    mats.append(scenes.mat((0.2, 0.3, 0.9)))
+    objs = []
+    for i in range(sc.object_count()):
+        o = sc.get_object(i)
+        objs.append([os.path.basename(o["model"]), tuple(np.float32(v) for v in o["position"]), o["rotation"], o["scale"], o["material_index"]])
+    p = np.array(objs[6][1], np.float32); p[1] += np.float32(0.5); objs[6][1] = tuple(p)
+    del objs[7]
+    objs.append(["cube.obj", (3.0, 1.0, 2.0), (0.0, 30.0, 0.0), (1.0, 1.0, 1.0), 9])
+    arrays = scenes.build_oracle(mats, [tuple(o) for o in objs]).bindings()
+    opc = scenes.make_pc(arrays, W, H, cam_pos=s[11]["pos"], look=s[11]["dir"])
+    acc = np.zeros((H, W, 4), np.float32)
+    for f in range(8):
+        opc["frame"] = f
+        res = O.render(arrays, O.pc_bytes(opc), W, H, accum=acc)
+        acc = res["accum"]
+    assert np.array_equal(decode_png(png), R.rgba32f_to_rgba8(res["out"]))
 
 
 import ctypes
