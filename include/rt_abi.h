@@ -65,7 +65,10 @@ enum {
      * nodes and triangles in the reference's order and the samples are added in sequence order:
      * same results. Other launches (one sample, debug views, counters) use kernel 0. The default:
      * fastest on scenes whose walks have a long tail (the default scene: +6.5 %), a few per cent
-     * slower than 0 on evenly built BVHs (a regular height field). */
+     * slower than 0 on evenly built BVHs (a regular height field). 4 = path waves + walker waves: a
+     * workgroup of 16 waves per compute unit; its path waves (12) run kernel 0's code except the walks of
+     * BVH parents, which they hand - one job per ray, through a ring in LDS - to the workgroup's walker
+     * waves (4), whose lanes take the next job as soon as they are free. Same arithmetic, same results. */
     RT_OPT_PIPELINE    = 2,
     /* Tile partition for multi-GPU tile split: this context renders only the
      * tiles t with t % RT_OPT_TILE_WORLD == RT_OPT_TILE_RANK (tiles are
@@ -112,6 +115,8 @@ enum {
      * builds, the debug views, pipelines 1 and 2 and dispatches with parentBVHCount below the uploaded
      * object count always use 0. */
     RT_OPT_TRAVERSAL = 17, RT_OPT_SAH_MAX_LEAF = 18,
+    /* Pipeline 4: walker waves per workgroup of 16 waves (default 4; the other waves are path waves). */
+    RT_OPT_TEAM_WALKERS = 19,
     /* Read-only (rt_get_option) facts about the uploaded scene: traversal stack entries a lane can
      * need (longest chain of two-child records), number of two-child records, and number of
      * triangle records in leaf order (a triangle that several leaves share counts once per leaf). */

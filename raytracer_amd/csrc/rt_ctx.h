@@ -48,6 +48,7 @@ struct rt_ctx {
     int fastObjects = 0;          // objects that walk a rebuilt tree
     size_t fastNodeCount = 0, fastTriCount = 0;
     int optTraversal = 0, sahMaxLeaf = 4;
+    int teamWalkers = 4;          // pipeline 4: walker waves per 16-wave workgroup
 
     // images
     int width = 0, height = 0;

@@ -49,6 +49,8 @@ hipError_t rt_launch_wf_path_fast(const DevScene*, const rt_push_constants*, con
                                   DevCounters*, int, int, int, int, int, hipStream_t);
 hipError_t rt_launch_wf_walk_strict(const DevScene*, const rt_push_constants*, const DevWavefront*, int, int, int, hipStream_t);
 hipError_t rt_launch_wf_walk_fast(const DevScene*, const rt_push_constants*, const DevWavefront*, int, int, int, hipStream_t);
+hipError_t rt_launch_teamkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, unsigned long long*, int, int, int, hipStream_t);
+hipError_t rt_launch_teamkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, unsigned long long*, int, int, int, hipStream_t);
 hipError_t rt_launch_math_strict(int, const float*, float*, size_t, hipStream_t);
 hipError_t rt_launch_math_fast(int, const float*, float*, size_t, hipStream_t);
 hipError_t rt_launch_resolve_strict(const void*, void*, size_t, float, hipStream_t);
@@ -615,7 +617,7 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
     // near-first traversal: path tracing on the lock-step kernels only; the counting builds and the debug
     // views always walk the reference's trees in the reference's order
     const DevScene* scene = &ctx->scene;
-    if (ctx->optTraversal == 1 && (ctx->optPipeline == 0 || ctx->optPipeline == 3) && pc.renderMode == 0 && !statsOnly &&
+    if (ctx->optTraversal == 1 && (ctx->optPipeline == 0 || ctx->optPipeline == 3 || ctx->optPipeline == 4) && pc.renderMode == 0 && !statsOnly &&
         pc.parentBVHCount == ctx->scene.objectCount) {
         int rc = ensureFastScene(ctx);
         if (rc != RT_OK) return rc;
@@ -631,6 +633,10 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
         auto fn = ctx->optFast ? rt_launch_schedkernel_fast : rt_launch_schedkernel_strict;
         e = fn(&ctx->scene, &pc, &L, ctx->accum, ctx->draw, statsOnly ? ctx->dCounters : nullptr, countBuild ? 1 : 0,
                statsOnly ? 1 : 0, ctx->dQueue, blocks, ctx->stream, diag);
+    } else if (ctx->optPipeline == 4 && pc.renderMode == 0 && !statsOnly && pc.raysPerPixel >= 1) {
+        // one workgroup of 16 waves per compute unit; its path waves pull tiles from a counter
+        auto fn = ctx->optFast ? rt_launch_teamkernel_fast : rt_launch_teamkernel_strict;
+        e = fn(scene, &pc, &L, ctx->accum, ctx->draw, ctx->dQueue, std::max(1, ctx->computeUnits), ctx->teamWalkers, ctx->wfRefill, ctx->stream);
     } else if (ctx->optPipeline == 3 && pc.renderMode == 0 && !statsOnly && pc.raysPerPixel >= 1 && (long long)frames * pc.raysPerPixel >= 2) {
         auto fn = ctx->optFast ? rt_launch_pairkernel_fast : rt_launch_pairkernel_strict;
         e = fn(scene, &pc, &L, ctx->accum, ctx->draw, ctx->stream);
@@ -716,7 +722,7 @@ int rt_set_option(rt_ctx* ctx, int option, int value) try
     switch (option) {
     case RT_OPT_FAST_MATH: ctx->optFast = value ? 1 : 0; return RT_OK;
     case RT_OPT_PIPELINE:
-        if (value < 0 || value > 3) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step), 1 (wave-scheduled), 2 (wavefront) or 3 (lock-step, two samples per lane)");
+        if (value < 0 || value > 4) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "pipeline must be 0 (lock-step), 1 (wave-scheduled), 2 (wavefront), 3 (lock-step, two samples per lane) or 4 (path waves + walker waves)");
         ctx->optPipeline = value;
         return RT_OK;
     case RT_OPT_WAVES_PER_CU:
@@ -743,6 +749,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value) try
     case RT_OPT_FRAMES_PER_LAUNCH:
         if (value < 1 || value > 4096) return rt_fail(ctx, RT_ERR_INVALID_ARG, "frames per launch must be in [1,4096]");
         ctx->framesPerLaunch = value;
+        return RT_OK;
+    case RT_OPT_TEAM_WALKERS:
+        if (value < 1 || value > 8) return rt_fail(ctx, RT_ERR_INVALID_ARG, "walker waves per workgroup must be in [1,8]");
+        ctx->teamWalkers = value;
         return RT_OK;
     case RT_OPT_TRAVERSAL:
         if (value != 0 && value != 1) return rt_fail(ctx, RT_ERR_INVALID_ARG, "traversal must be 0 (reference order) or 1 (near-first on rebuilt trees)");
@@ -789,6 +799,7 @@ int rt_get_option(rt_ctx* ctx, int option, int* value) try
     case RT_OPT_WF_WALK_WAVES: *value = ctx->wfWalkWaves; return RT_OK;
     case RT_OPT_WF_PARTS: *value = ctx->wfParts; return RT_OK;
     case RT_OPT_FRAMES_PER_LAUNCH: *value = ctx->framesPerLaunch; return RT_OK;
+    case RT_OPT_TEAM_WALKERS: *value = ctx->teamWalkers; return RT_OK;
     case RT_OPT_TRAVERSAL: *value = ctx->optTraversal; return RT_OK;
     case RT_OPT_SAH_MAX_LEAF: *value = ctx->sahMaxLeaf; return RT_OK;
     case RT_INFO_FAST_OBJECTS: case RT_INFO_FAST_RECORDS: case RT_INFO_FAST_TRIANGLES: case RT_INFO_FAST_STACK_DEPTH: {
@@ -957,7 +968,7 @@ int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, 
     rt_push_constants p = *pc;
     // the lock-step kernel can run several consecutive frames of a pixel in one launch (same
     // arithmetic in the same order, one read and one write of the accumulation pixel)
-    const bool fuse = (ctx->optPipeline == 0 || ctx->optPipeline == 3) && pc->renderMode == 0 && pc->raysPerPixel >= 1 && ctx->framesPerLaunch > 1;
+    const bool fuse = (ctx->optPipeline == 0 || ctx->optPipeline == 3 || ctx->optPipeline == 4) && pc->renderMode == 0 && pc->raysPerPixel >= 1 && ctx->framesPerLaunch > 1;
     const int group = fuse ? ctx->framesPerLaunch : 1;
     for (int k = 0; k < count; k += group) {
         const int n = std::min(group, count - k);

@@ -2194,6 +2194,8 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
     }
 }
 
+#include "rt_team.inl"
+
 // draw = gamma(accum.rgb * 1/total_frames), draw.a = accum.a (raytrace.comp:794-801)
 __global__ __launch_bounds__(256) void RT_SYM(rt_resolve_kernel)(const float4* __restrict__ accum, float4* __restrict__ out,
                                                                  size_t pixels, float multiplier)
