@@ -86,6 +86,10 @@ struct DevScene {
      * inside an object whose root is such a record the walk enters the nearer child first. INT32_MAX
      * in the reference-order scene. */
     int32_t            nearFirstBase;
+    /* 1: the hit GetHit returns does not depend on the order in which the parents are visited (the
+     * near-first scene when no object is scaled below 1), so parents may be tested concurrently and their
+     * hits merged by distance. 0 in the reference-order scene. */
+    int32_t            orderFree;
 };
 
 #if defined(__HIPCC__)

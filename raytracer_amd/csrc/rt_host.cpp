@@ -466,6 +466,9 @@ int ensureFastScene(rt_ctx* ctx)
     f.anyLeafCount = leafCount;
     f.stackDepth = std::max(1, std::min(RT_MAX_STACK, depth));
     f.nearFirstBase = nearFirstBase;
+    f.orderFree = 1;
+    for (size_t i = 0; i < P; ++i)
+        if (objects[i].root > RT_REF_LIVE_MIN && !eligible[i]) f.orderFree = 0;
     ctx->fastScene = f;
     ctx->fastObjects = rebuilt;
     ctx->fastNodeCount = nodes.size();
@@ -896,6 +899,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b) try
     ctx->scene.objectCount = (int32_t)rl.dObjects.size();
     ctx->scene.stackDepth = std::max(1, std::min(RT_MAX_STACK, rl.maxDepth));
     ctx->scene.nearFirstBase = 0x7fffffff;
+    ctx->scene.orderFree = 0;
     ctx->hStackDepth = ctx->scene.stackDepth;
     ctx->nodeCount = rl.dNodes.size();
     ctx->triCount = rl.dTris.size();

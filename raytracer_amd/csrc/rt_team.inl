@@ -25,9 +25,10 @@
 // carried from parent to parent, so the images are those of the lock-step kernels bit for bit.
 
 #define RT_TEAM_WAVES 16
-#define RT_TEAM_RING 1024            /* ring entries; at most (16 - walkers) * 64 jobs are outstanding */
+#define RT_TEAM_RING 2048            /* ring entries; at most (16 - walkers) * 2 * 64 jobs are outstanding */
 #define RT_TEAM_IN 10                /* dwords per job, in: origin 0-2, direction 3-5, closest 6, meta 7, mask 8-9 */
 #define RT_TEAM_OUT 6                /* dwords per job, out: closest, tLocal, u, v, object, triangle */
+#define RT_TEAM_SLOTS 2              /* jobs a lane can have in flight: a regular ray and a shadow ray */
 #define RT_TEAM_EMPTY (-1)
 #define RT_TEAM_NEXT 0x7ffffffd      /* walker lane: between two parents of its job */
 #define RT_TEAM_ANYHIT 0x80000000u   /* job meta: stop at the first accepted hit */
@@ -38,10 +39,10 @@ namespace {
 // Workgroup-shared state, carved out of dynamic LDS.
 struct TeamShared {
     unsigned* ctrl;       // [0] ring head (consumers), [1] ring tail (producers), [2] path waves finished
-    int* ring;            // RT_TEAM_RING slot numbers (path wave * 64 + lane) or RT_TEAM_EMPTY
+    int* ring;            // RT_TEAM_RING job numbers or RT_TEAM_EMPTY
     unsigned* pending;    // per path wave: jobs of its current batch not yet done
-    float* in;            // [path wave][RT_TEAM_IN][64]
-    float* out;           // [path wave][RT_TEAM_OUT][64]
+    float* in;            // [path wave][slot][RT_TEAM_IN][64]; a job's number is (path wave * RT_TEAM_SLOTS + slot) * 64 + lane
+    float* out;           // [path wave][slot][RT_TEAM_OUT][64]
     uint2* stacks;        // [walker wave][depth][64]
 };
 
@@ -52,8 +53,8 @@ __device__ __forceinline__ TeamShared team_shared(void* base, int pathWaves, int
     t.ctrl = reinterpret_cast<unsigned*>(p); p += 64;
     t.ring = reinterpret_cast<int*>(p); p += RT_TEAM_RING * sizeof(int);
     t.pending = reinterpret_cast<unsigned*>(p); p += 64;
-    t.in = reinterpret_cast<float*>(p); p += (size_t)pathWaves * RT_TEAM_IN * 64 * sizeof(float);
-    t.out = reinterpret_cast<float*>(p); p += (size_t)pathWaves * RT_TEAM_OUT * 64 * sizeof(float);
+    t.in = reinterpret_cast<float*>(p); p += (size_t)pathWaves * RT_TEAM_SLOTS * RT_TEAM_IN * 64 * sizeof(float);
+    t.out = reinterpret_cast<float*>(p); p += (size_t)pathWaves * RT_TEAM_SLOTS * RT_TEAM_OUT * 64 * sizeof(float);
     t.stacks = reinterpret_cast<uint2*>(p);
     (void)walkers; (void)stackDepth;
     return t;
@@ -69,41 +70,66 @@ struct TeamPath {
     int lane;
 };
 
-// Hands the jobs of the lanes in `emit` to the walkers and waits for them. Whole wave.
-// closest / best are updated for the lanes whose walk found something nearer.
-__device__ __forceinline__ void team_walk(const TeamPath& tp, bool emit, V3 org, V3 dirN, unsigned long long mask, unsigned meta, Best& best)
+// Hands the jobs of the lanes in `emit` (slot k of each lane) to the walkers. Whole wave.
+__device__ __forceinline__ void team_emit(const TeamPath& tp, int k, bool emit, V3 org, V3 dirN, float closest, unsigned long long mask, unsigned meta)
 {
     const unsigned long long m = __ballot(emit);
     if (m == 0) return;
     const unsigned n = (unsigned)__popcll(m);
-    float* in = tp.sh.in + (size_t)tp.wave * RT_TEAM_IN * 64 + tp.lane;
+    const int first = (tp.wave * RT_TEAM_SLOTS + k) * 64;
+    float* in = tp.sh.in + (size_t)(tp.wave * RT_TEAM_SLOTS + k) * RT_TEAM_IN * 64 + tp.lane;
     if (emit) {
         in[0 * 64] = org.x; in[1 * 64] = org.y; in[2 * 64] = org.z;
         in[3 * 64] = dirN.x; in[4 * 64] = dirN.y; in[5 * 64] = dirN.z;
-        in[6 * 64] = best.closest;
+        in[6 * 64] = closest;
         in[7 * 64] = __uint_as_float(meta);
         in[8 * 64] = __uint_as_float((unsigned)mask);
         in[9 * 64] = __uint_as_float((unsigned)(mask >> 32));
     }
-    if (tp.lane == 0) __hip_atomic_store(&tp.sh.pending[tp.wave], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // jobs and counter before their ring entries
     unsigned base = 0;
-    if (tp.lane == 0) base = __hip_atomic_fetch_add(&tp.sh.ctrl[1], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (tp.lane == 0) {
+        __hip_atomic_fetch_add(&tp.sh.pending[tp.wave], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = __hip_atomic_fetch_add(&tp.sh.ctrl[1], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // jobs and counter before their ring entries
     base = (unsigned)__shfl((int)base, 0, 64);
     if (emit) {
         const unsigned rank = (unsigned)__popcll(m & ((1ull << tp.lane) - 1ull));
-        __hip_atomic_store(&tp.sh.ring[(base + rank) & (RT_TEAM_RING - 1)], tp.wave * 64 + tp.lane, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&tp.sh.ring[(base + rank) & (RT_TEAM_RING - 1)], first + tp.lane, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    while (team_load(&tp.sh.pending[tp.wave]) != 0) __builtin_amdgcn_s_sleep(2);
+}
+
+// Sleeps until every job this wave has emitted is done. Whole wave.
+__device__ __forceinline__ void team_wait(const TeamPath& tp)
+{
+#ifdef RT_SECTION_TIMERS
+    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+    while (team_load(&tp.sh.pending[tp.wave]) != 0) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (emit) {
-        const float* out = tp.sh.out + (size_t)tp.wave * RT_TEAM_OUT * 64 + tp.lane;
-        const int object = __float_as_int(out[4 * 64]);
-        if (object >= 0) {
-            best.closest = out[0 * 64]; best.tLocal = out[1 * 64]; best.u = out[2 * 64]; best.v = out[3 * 64];
-            best.object = object; best.tri = __float_as_int(out[5 * 64]);
-        }
-    }
+#ifdef RT_SECTION_TIMERS
+    if (tp.lane == 0) atomicAdd(&g_sectionCycles[4], __builtin_amdgcn_s_memtime() - w0);
+#endif
+}
+
+// The answer to this lane's job in slot k: true, with `best` filled, when the walk accepted a hit.
+__device__ __forceinline__ bool team_result(const TeamPath& tp, int k, Best& best)
+{
+    const float* out = tp.sh.out + (size_t)(tp.wave * RT_TEAM_SLOTS + k) * RT_TEAM_OUT * 64 + tp.lane;
+    const int object = __float_as_int(out[4 * 64]);
+    if (object < 0) return false;
+    best.closest = out[0 * 64]; best.tLocal = out[1 * 64]; best.u = out[2 * 64]; best.v = out[3 * 64];
+    best.object = object; best.tri = __float_as_int(out[5 * 64]);
+    return true;
+}
+
+// Emit, wait, take the answer: the walk of a run of BVH parents in the middle of an ordered object loop.
+__device__ __forceinline__ void team_walk(const TeamPath& tp, bool emit, V3 org, V3 dirN, unsigned long long mask, unsigned meta, Best& best)
+{
+    if (!__any(emit)) return;
+    team_emit(tp, 0, emit, org, dirN, best.closest, mask, meta);
+    team_wait(tp);
+    if (emit) (void)team_result(tp, 0, best);
 }
 
 // GetHit (raytrace.comp:448-610) as a path wave runs it: trace() with the walks of the BVH parents
@@ -231,6 +257,131 @@ __device__ __forceinline__ V3 ray_colour_team(const DevScene& S, const rt_push_c
     return result;
 }
 
+// RayColour for scenes whose GetHit does not depend on the visiting order (DevScene::orderFree). Per
+// bounce the wave hands BOTH rays it has to trace - the shadow ray of the hit just shaded and the
+// scattered ray - to the walkers first (every BVH parent whose box a ray can enter, in one job per ray),
+// tests the leaf parents itself while the walkers work, then waits once and merges by distance (on a
+// tie the parent that comes first in the scene wins, as in the ordered loop). The sun term of a hit is
+// added when its shadow ray's answer is in, one iteration later, still before anything the next hit
+// adds: the additions to `result` keep the reference's order.
+__device__ __forceinline__ V3 ray_colour_team_async(const DevScene& S, const rt_push_constants& pc, Ray ray, bool alive, uint32_t seed,
+                                                    V3 sunDirN, const TeamPath& tp)
+{
+    V3 result = mk(0.0f, 0.0f, 0.0f);
+    V3 throughput = mk(1.0f, 1.0f, 1.0f);
+    const int bounces = pc.maxBounces + 1;
+    const int P = S.objectCount, leafCount = S.anyLeafCount;
+    const float tMin = 0.001f;
+    const unsigned metaBase = (unsigned)leafCount | RT_TEAM_PERMUTE;
+    V3 sunInv;
+    const bool sunPar = lean_inverse(sunDirN, sunInv);
+    bool shadow = false;
+    V3 so = mk(0.0f, 0.0f, 0.0f), sunTerm = mk(0.0f, 0.0f, 0.0f);
+    for (int bounce = 0; ; ++bounce) {
+        const bool want = alive && bounce < bounces;
+        if (!__any(want || shadow)) break;
+        const V3 dirN = normalize3(ray.d);
+        V3 winv;
+        const bool parW = lean_inverse(dirN, winv) && want;
+        const bool anyParR = __any(parW), anyParS = sunPar && __any(shadow);
+
+        // which BVH parents (positions leafCount.. of the any-hit order) each of the two rays can enter
+        unsigned long long maskR = 0, maskS = 0;
+        for (int pos = leafCount; pos < P; ++pos) {
+            const DevObject* ob = S.objects + S.anyOrder[pos];   // wave-uniform
+            const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+            float E;
+            if (want && (anyParR ? lean_box<true>(ray.o, winv, bmn, bmx, tMin, E) : lean_box<false>(ray.o, winv, bmn, bmx, tMin, E)))
+                maskR |= 1ull << (pos - leafCount);
+            if (shadow && (anyParS ? lean_box<true>(so, sunInv, bmn, bmx, tMin, E) : lean_box<false>(so, sunInv, bmn, bmx, tMin, E)))
+                maskS |= 1ull << (pos - leafCount);
+        }
+        const bool jobR = want && maskR != 0, jobS = shadow && maskS != 0;
+        const bool anyJob = __any(jobR || jobS);
+        team_emit(tp, 0, jobR, ray.o, dirN, 1e20f, maskR, metaBase);
+        team_emit(tp, 1, jobS, so, sunDirN, 1e20f, maskS, metaBase | RT_TEAM_ANYHIT);
+
+        // the leaf parents, here, while the walkers work: closest hit for the regular ray, any hit for the shadow ray
+        Best best;
+        best_reset(best, 1e20f);
+        bool blocked = false;
+        for (int pos = 0; pos < leafCount; ++pos) {
+            const int i = S.anyOrder[pos];
+            const DevObject* ob = S.objects + i;   // wave-uniform
+            const int root = ob->root;
+            if (!(root > RT_REF_LIVE_MIN)) continue;
+            const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+            float E;
+            bool okR = want && (anyParR ? lean_box<true>(ray.o, winv, bmn, bmx, tMin, E) : lean_box<false>(ray.o, winv, bmn, bmx, tMin, E)) &&
+                       (best.closest > E);
+            bool okS = shadow && !blocked && (anyParS ? lean_box<true>(so, sunInv, bmn, bmx, tMin, E) : lean_box<false>(so, sunInv, bmn, bmx, tMin, E));
+            if (!__any(okR || okS)) continue;
+            const V3 loR = xform(ob->inv, ray.o, 1.0f), ldR = normalize3(xform(ob->inv, dirN, 0.0f));
+            const V3 loS = xform(ob->inv, so, 1.0f), ldS = normalize3(xform(ob->inv, sunDirN, 0.0f));
+            const float4* rec = reinterpret_cast<const float4*>(S.tris + ~root);
+            for (;;) {
+                const float4 t0 = rec[0], t1 = rec[1], t2 = rec[2];
+                if (okR) (void)triangle_hit(t0, t1, t2, loR, ldR, ob->fwd, ray.o, dirN, tMin, i, best);
+                if (okS) {
+                    Best sb;
+                    best_reset(sb, 1e20f);
+                    if (triangle_hit(t0, t1, t2, loS, ldS, ob->fwd, so, sunDirN, tMin, i, sb)) { blocked = true; okS = false; }
+                }
+                if (__float_as_int(t0.w) <= 1) break;
+                rec += 3;
+            }
+        }
+
+        if (anyJob) team_wait(tp);
+        if (jobR) {
+            Best w;
+            if (team_result(tp, 0, w) && (w.closest < best.closest || (w.closest == best.closest && w.object < best.object))) best = w;
+        }
+        if (jobS && !blocked) {
+            Best w;
+            if (team_result(tp, 1, w)) blocked = true;
+        }
+        if (shadow && !blocked) result = result + sunTerm;
+        shadow = false;
+
+        if (want) {
+            HitRec rec;
+            finish_hit(S, ray.o, dirN, best, rec);
+            if (!rec.hit) {
+                result = result + throughput * environment_colour(pc, ray.d);
+                alive = false;
+            } else if (!rec.frontFace) {
+                alive = false;
+            } else {
+                const DevMaterial m = load_material(S, rec.matIndex);
+                const V3 emitted = ld3(m.colour) * m.emission;
+                result = result + throughput * emitted;
+                if (m.emission > 0.0f) {
+                    alive = false;
+                } else {
+                    const V3 negSun = -ld3(pc.sunDirection);
+                    const float nDotL = gmax(dot3(rec.normal, negSun), 0.0f);
+                    if (nDotL > 0.0f) {
+                        shadow = true;
+                        so = rec.point + rec.normal * 0.01f;
+                        const V3 sun = ld3(pc.sunColour) * pc.sunIntensity;
+                        const float INV_PI = 0.31830988618f;
+                        const V3 direct = sun * (nDotL * INV_PI);
+                        if (m.refractionIndex == 0.0f) sunTerm = (throughput * ld3(m.colour)) * direct;
+                        else sunTerm = (throughput * reflectance(nDotL, m.refractionIndex)) * direct;
+                    }
+                    V3 attenuation;
+                    Ray scattered;
+                    material_scatter(m, ray.d, rec, seed, attenuation, scattered);
+                    throughput = throughput * attenuation;
+                    ray = scattered;
+                }
+            }
+        }
+    }
+    return result;
+}
+
 // A walker wave: every lane takes jobs from the ring and walks them, one step per iteration.
 __device__ __forceinline__ void team_walker(const DevScene& S, const TeamShared& sh, int pathWaves, uint2* stack, int lane, int refillMin)
 {
@@ -247,6 +398,10 @@ __device__ __forceinline__ void team_walker(const DevScene& S, const TeamShared&
     t.obj = 0; t.cur = RT_TEAM_NEXT; t.sp = 0;
     const bool tightScene = S.nearFirstBase != 0x7fffffff;
 
+#ifdef RT_SECTION_TIMERS
+    unsigned long long dIter = 0, dLanes = 0, dIdle = 0, dJobs = 0;
+    const unsigned long long dStart = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         // ---- refill, only when enough lanes are free (or nothing is being walked): free lanes reserve the
         // next ring positions with one atomic for the wave and look whether theirs is filled ----
@@ -266,7 +421,7 @@ __device__ __forceinline__ void team_walker(const DevScene& S, const TeamShared&
                     __hip_atomic_store(entry, RT_TEAM_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     slot = v;
                     resv = -1;
-                    const float* in = sh.in + (size_t)(v >> 6) * RT_TEAM_IN * 64 + (v & 63);
+                    const float* in = sh.in + (size_t)(v >> 6) * RT_TEAM_IN * 64 + (v & 63);   // v >> 6 = path wave * RT_TEAM_SLOTS + slot
                     t.rayO = mk(in[0 * 64], in[1 * 64], in[2 * 64]);
                     t.dirN = mk(in[3 * 64], in[4 * 64], in[5 * 64]);
                     t.best.closest = in[6 * 64];
@@ -277,7 +432,13 @@ __device__ __forceinline__ void team_walker(const DevScene& S, const TeamShared&
                     t.cur = RT_TEAM_NEXT;
                 }
             }
+#ifdef RT_SECTION_TIMERS
+            dJobs += __popcll(__ballot(slot >= 0)) - walking;
+#endif
             if (!__any(slot >= 0)) {
+#ifdef RT_SECTION_TIMERS
+                dIdle++;
+#endif
                 // nothing to do: leave when every path wave of the workgroup has finished (no job is outstanding then)
                 if (team_load(&sh.ctrl[2]) >= (unsigned)pathWaves) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -285,6 +446,9 @@ __device__ __forceinline__ void team_walker(const DevScene& S, const TeamShared&
             }
         }
 
+#ifdef RT_SECTION_TIMERS
+        dIter++; dLanes += __popcll(__ballot(slot >= 0));
+#endif
         if (slot >= 0) {
             // between two parents: the job is done, or its next parent is due
             if (t.cur == RT_TEAM_NEXT) {
@@ -294,7 +458,7 @@ __device__ __forceinline__ void team_walker(const DevScene& S, const TeamShared&
                     out[0 * 64] = t.best.closest; out[1 * 64] = t.best.tLocal; out[2 * 64] = t.best.u; out[3 * 64] = t.best.v;
                     out[4 * 64] = __int_as_float(t.best.object); out[5 * 64] = __int_as_float(t.best.tri);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __hip_atomic_fetch_sub(&sh.pending[slot >> 6], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_sub(&sh.pending[(slot >> 6) / RT_TEAM_SLOTS], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     slot = -1;
                 } else {
                     const int bit = __ffsll((long long)mask) - 1;
@@ -371,6 +535,12 @@ __device__ __forceinline__ void team_walker(const DevScene& S, const TeamShared&
             t.cur = next;
         }
     }
+#ifdef RT_SECTION_TIMERS
+    if (lane == 0) {
+        atomicAdd(&g_sectionCycles[0], dIter); atomicAdd(&g_sectionCycles[1], dLanes); atomicAdd(&g_sectionCycles[2], dIdle);
+        atomicAdd(&g_sectionCycles[3], dJobs); atomicAdd(&g_sectionCycles[6], __builtin_amdgcn_s_memtime() - dStart);
+    }
+#endif
 }
 
 } // namespace
@@ -395,6 +565,9 @@ __global__ __launch_bounds__(RT_TEAM_WAVES * 64) void RT_SYM(rt_teamkernel)(DevS
         return;
     }
 
+#ifdef RT_SECTION_TIMERS
+    const unsigned long long teamStart = __builtin_amdgcn_s_memtime();
+#endif
     TeamPath tp;
     tp.sh = sh;
     tp.wave = wave - walkers;
@@ -405,6 +578,8 @@ __global__ __launch_bounds__(RT_TEAM_WAVES * 64) void RT_SYM(rt_teamkernel)(DevS
     const int rpp = pc.raysPerPixel;
     const float raysPerPixelRatio = 1.0f / (float)rpp;
     const V3 sunDirN = normalize3(-ld3(pc.sunDirection));
+    // parents may be tested concurrently when the scene allows it and one 64-bit mask can name every BVH parent
+    const bool concurrent = S.orderFree != 0 && pc.parentBVHCount == S.objectCount && S.objectCount - S.anyLeafCount <= 64;
     for (;;) {
         unsigned long long item = 0;
         if (lane == 0) item = atomicAdd(queue, 1ull);
@@ -428,7 +603,8 @@ __global__ __launch_bounds__(RT_TEAM_WAVES * 64) void RT_SYM(rt_teamkernel)(DevS
             for (int i = 0; i < rpp; ++i) {
                 const uint32_t seed = seed_from_coords((uint32_t)x, (uint32_t)y, frame, (uint32_t)i);
                 const Ray ray = get_ray(pc, x, y, seed);
-                nc = nc + ray_colour_team(S, pc, ray, inside, seed, sunDirN, tp);
+                nc = nc + (concurrent ? ray_colour_team_async(S, pc, ray, inside, seed, sunDirN, tp)
+                                      : ray_colour_team(S, pc, ray, inside, seed, sunDirN, tp));
             }
             if (inside) {
                 acc = accum[idx];
@@ -445,6 +621,9 @@ __global__ __launch_bounds__(RT_TEAM_WAVES * 64) void RT_SYM(rt_teamkernel)(DevS
             out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
         }
     }
+#ifdef RT_SECTION_TIMERS
+    if (lane == 0) atomicAdd(&g_sectionCycles[5], __builtin_amdgcn_s_memtime() - teamStart);
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_fetch_add(&sh.ctrl[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -457,7 +636,7 @@ extern "C" hipError_t RT_SYM(rt_launch_teamkernel)(const DevScene* S, const rt_p
     if (waves <= 0 || workgroups <= 0) return hipSuccess;
     if (walkers < 1 || walkers > RT_TEAM_WAVES - 1) return hipErrorInvalidValue;
     const int pathWaves = RT_TEAM_WAVES - walkers;
-    const size_t lds = 64 + RT_TEAM_RING * sizeof(int) + 64 + (size_t)pathWaves * (RT_TEAM_IN + RT_TEAM_OUT) * 64 * sizeof(float) +
+    const size_t lds = 64 + RT_TEAM_RING * sizeof(int) + 64 + (size_t)pathWaves * RT_TEAM_SLOTS * (RT_TEAM_IN + RT_TEAM_OUT) * 64 * sizeof(float) +
                        (size_t)walkers * (size_t)S->stackDepth * 64 * sizeof(uint2);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);

@@ -75,7 +75,7 @@ def oracle(arrays, opc, frames, W, H, window=None):
     return res["accum"], res["out"]
 
 
-@pytest.mark.parametrize("pipeline", [3, 0], ids=["two-samples", "lockstep"])
+@pytest.mark.parametrize("pipeline", [3, 0, 4], ids=["two-samples", "lockstep", "team"])
 def test_default_scene_1spp_and_converged(R, default_scene_arrays, pipeline):
     r = R.Renderer(0)
     try:
@@ -158,7 +158,7 @@ def test_mixed_material_scene(R):
         W, H = 320, 180
         opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 2.5, 8.0), look=(0.0, -0.15, -1.0), fov=60.0, maxBounces=5)
         want_acc, want_out = oracle(arrays, opc, [0, 1], W, H)
-        for pipeline in (3, 0):
+        for pipeline in (3, 0, 4):
             acc, out = render(R, r, opc, [0, 1], W, H, 1, pipeline)
             same, ok = shares(acc, want_acc)
             assert ok >= 0.995 and same >= 0.99, (pipeline, same, ok)
@@ -217,6 +217,11 @@ def test_generated_configs_full_size(R, name, tmp_path_factory):
         assert ok >= 0.995 and same >= 0.999, (same, ok)
         acc0, out0 = render(R, r, opc, [0, 1], W, H, 1, 0)
         assert shares(acc0, ref_acc)[1] >= 0.995
+        # path waves + walker waves: the near-first image of the lock-step kernel, and (reference order) the oracle's
+        acc4, out4 = render(R, r, opc, [0, 1], W, H, 1, 4)
+        assert shares(acc4, acc0)[0] >= 0.9999
+        acc4, out4 = render(R, r, opc, [0, 1], W, H, 0, 4)
+        assert np.array_equal(bits(acc4), bits(ref_acc)) and np.array_equal(bits(out4), bits(ref_out))
         for win in ([(900, 520, 1028, 568), (300, 700, 396, 748)] if name == "heightfield" else [(900, 500, 996, 548), (600, 640, 664, 688)]):
             x0, y0, x1, y1 = win
             wa, wo = oracle(arrays, opc, [0, 1], W, H, window=win)

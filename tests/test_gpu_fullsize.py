@@ -134,7 +134,7 @@ def test_generated_configs_full_size(R, generated, name):
         r.upload_scene(scene.buffers()); r.resize(W, H)
         assert r.get_option(R.RT_INFO_STACK_DEPTH) <= 31
         images, stats = {}, {}
-        for pipeline in (3, 0, 2):
+        for pipeline in (3, 0, 2, 4):
             r.set_option(R.RT_OPT_PIPELINE, pipeline)
             r.clear_accumulation()
             pc.frame = 0
@@ -143,7 +143,7 @@ def test_generated_configs_full_size(R, generated, name):
             pc.frame = 1
             st = r.frame_stats(pc)
             stats[pipeline] = (st.rays, st.bvhNodeTests, st.triangleTests, st.samples)
-        for pipeline in (0, 2):
+        for pipeline in (0, 2, 4):
             assert np.array_equal(bits(images[pipeline][0]), bits(images[3][0])), pipeline
             assert np.array_equal(bits(images[pipeline][1]), bits(images[3][1])), pipeline
             assert stats[pipeline] == stats[3], (pipeline, stats)

@@ -29,7 +29,7 @@ def R():
     return raytracer_amd
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2, 3], ids=["lockstep", "scheduled", "wavefront", "two-samples"])
+@pytest.fixture(scope="module", params=[0, 1, 2, 3, 4], ids=["lockstep", "scheduled", "wavefront", "two-samples", "team"])
 def rdr(R, default_scene_arrays, request):
     """One renderer per kernel choice: every test that takes `rdr` runs on all pipelines."""
     r = R.Renderer(0)
@@ -214,7 +214,7 @@ def test_converged_psnr(R, rdr, default_scene_arrays):
     assert psnr >= 45.0, psnr
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2], ids=["lockstep", "scheduled", "wavefront"])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 4], ids=["lockstep", "scheduled", "wavefront", "team"])
 def test_mixed_material_scene(R, pipeline):
     """Glass (exp/pow), mirror, fuzzy metal, emitter, open sky (acos/exp/pow), sub-unit and
     non-uniform scales, a model without normals and one with a 287-triangle leaf: bit-exact."""
@@ -586,6 +586,8 @@ def test_error_paths(R, default_scene_arrays):
             r.resize(0, 5)
         with pytest.raises(R.RtError):
             r.set_option(R.RT_OPT_PIPELINE, 7)
+        with pytest.raises(R.RtError):
+            r.set_option(R.RT_OPT_TEAM_WALKERS, 0)
         # invalid scenes are rejected at upload instead of faulting the GPU
         bad = [a.copy() for a in default_scene_arrays]
         bad[14][5] = 10 ** 6                           # child index out of range
