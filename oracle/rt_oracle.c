@@ -256,16 +256,26 @@ static inline v3 sample_square(uint32_t* seed)
     return V(x - 0.5f, y - 0.5f, 0.0f);
 }
 
+/* The reference's two rejection loops have no exit but acceptance, and its generator is a fixed
+ * permutation of the 32-bit states: a state on a short cycle whose draws are all rejected loops for
+ * ever (the shader would hang the GPU). That does happen at production sample counts - at 3840x2160,
+ * frame 1010, pixel (3563, 2062), sample 0, the Lambert branch never leaves RandomUnitVector (found by
+ * enumerating frames 0..1023 of that size). The reference defines no value for such a sample, so this
+ * restatement and the kernels give up after REJECTION_CAP rounds and return the zero vector: no lens
+ * offset, no fuzz, and a Lambert direction equal to the normal (MaterialScatter's NearZero branch). */
+#define REJECTION_CAP 65536
+
 /* Random.glsl:51-60 */
 static inline v3 random_in_unit_disk(uint32_t* seed)
 {
     *seed += 1u;
-    for (;;) {
+    for (int round = 0; round < REJECTION_CAP; ++round) {
         float px = rng_float_in_range(-1.0f, 1.0f, seed);
         float py = rng_float_in_range(-1.0f, 1.0f, seed);
         v3 p = V(px, py, 0.0f);
         if (sqrtf(vlength(p)) < 1.0f) return p;
     }
+    return V(0.0f, 0.0f, 0.0f);
 }
 
 /* Random.glsl:62-66 */
@@ -282,7 +292,7 @@ static inline v3 random_vector(uint32_t* seed)
 static inline v3 random_unit_vector(uint32_t* seed)
 {
     *seed += 1u;
-    for (;;) {
+    for (int round = 0; round < REJECTION_CAP; ++round) {
         v3 p = random_vector(seed);
         float lensq = vlength(p) * vlength(p);
         if (0.0f < lensq && lensq <= 1.0f) {
@@ -290,6 +300,14 @@ static inline v3 random_unit_vector(uint32_t* seed)
             return V(p.x / l, p.y / l, p.z / l);
         }
     }
+    return V(0.0f, 0.0f, 0.0f);
+}
+
+/* exported for tests: RandomUnitVector from a generator state */
+void orc_random_unit_vector(uint32_t seed, float out3[3])
+{
+    v3 u = random_unit_vector(&seed);
+    out3[0] = u.x; out3[1] = u.y; out3[2] = u.z;
 }
 
 /* Random.glsl:80-88 */

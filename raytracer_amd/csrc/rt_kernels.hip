@@ -108,11 +108,19 @@ __device__ __forceinline__ uint32_t seed_from_coords(uint32_t x, uint32_t y, uin
     s = s ^ (s >> 16);
     return s;
 }
+// The shader's two rejection loops end only on acceptance, and its generator is a fixed permutation of
+// the 32-bit states: a state on a short cycle whose draws are all rejected never leaves the loop (at
+// 3840x2160, frame 1010, pixel (3563, 2062), sample 0 does exactly that in RandomUnitVector; the shader
+// would hang the GPU there). The reference defines no value for such a sample: the loops here give up
+// after RT_REJECTION_CAP rounds and return the zero vector (no lens offset, no fuzz, a Lambert direction
+// equal to the normal through MaterialScatter's NearZero branch).
+#define RT_REJECTION_CAP 65536
+
 // Random.glsl:68-78 (with RandomVector :62-66 inlined). 1e-160 reads as 0 in f32.
 __device__ __forceinline__ V3 random_unit_vector(uint32_t& seed)
 {
     seed += 1u;
-    for (;;) {
+    for (int round = 0; round < RT_REJECTION_CAP; ++round) {
         seed += 1u;
         float x = rng_range(-1.0f, 1.0f, seed);
         float y = rng_range(-1.0f, 1.0f, seed);
@@ -125,6 +133,7 @@ __device__ __forceinline__ V3 random_unit_vector(uint32_t& seed)
             return mk(p.x / l, p.y / l, p.z / l);
         }
     }
+    return mk(0.0f, 0.0f, 0.0f);
 }
 // Random.glsl:80-88
 __device__ __forceinline__ V3 random_on_hemisphere(V3 normal, uint32_t& seed)
@@ -591,12 +600,11 @@ __device__ __forceinline__ Ray get_ray(const rt_push_constants& pc, int px, int 
         origin = ld3(pc.cameraPosition);
     } else {
         uint32_t s2 = seed + 1u;
-        V3 p;
-        for (;;) {
+        V3 p = mk(0.0f, 0.0f, 0.0f);
+        for (int round = 0; round < RT_REJECTION_CAP; ++round) {
             float dx = rng_range(-1.0f, 1.0f, s2);
             float dy = rng_range(-1.0f, 1.0f, s2);
-            p = mk(dx, dy, 0.0f);
-            if (sqrtf(length3(p)) < 1.0f) break;
+            if (sqrtf(length3(mk(dx, dy, 0.0f))) < 1.0f) { p = mk(dx, dy, 0.0f); break; }
         }
         origin = (ld3(pc.cameraPosition) + ld3(pc.defocusDiskU) * p.x) + ld3(pc.defocusDiskV) * p.y;
     }

@@ -27,6 +27,7 @@ def lib():
         L.orc_rng_draw.restype = C.c_uint32
         L.orc_rng_draw.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
         L.orc_sample_square.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
+        L.orc_random_unit_vector.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
         L.orc_math_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_scene_new.restype = C.c_void_p
         L.orc_scene_free.argtypes = [C.c_void_p]
@@ -71,6 +72,13 @@ def sample_square(seed):
     out = (C.c_float * 2)()
     lib().orc_sample_square(seed, out)
     return float(out[0]), float(out[1])
+
+
+def random_unit_vector(state):
+    """RandomUnitVector (Random.glsl:68-78) from a generator state -> (x, y, z)."""
+    out = (C.c_float * 3)()
+    lib().orc_random_unit_vector(state, out)
+    return float(out[0]), float(out[1]), float(out[2])
 
 
 def obj_corners(path):

@@ -199,3 +199,46 @@ def test_default_scene_3840x2160_one_launch(R, default_scene_arrays):
         assert np.array_equal(bits(acc[850:898, 1850:1978]), bits(wa))
     finally:
         r.close()
+
+
+@pytest.mark.timeout(120)
+def test_sample_whose_rejection_loop_never_accepts(R, default_scene_arrays):
+    """3840x2160, frame 1010, pixel (3563, 2062): the Lambert branch of that sample enters RandomUnitVector
+    on a generator state from which no draw is ever accepted (tests/test_oracle.py shows the cycle); the
+    reference shader would never finish this frame. The kernels cut the loop off as the oracle does: the
+    64x64 tile that holds the pixel (rendered alone, through the tile partition) is the oracle's, bit for
+    bit, on every kernel that path-traces."""
+    from raytracer_amd.distributed import tile_of_position
+    W, H, frame, px, py = 3840, 2160, 1010, 3563, 2062
+    tiles_x, tiles_y = W // 64, (H + 63) // 64
+    pos = next(p for p in range(tiles_x * tiles_y) if tile_of_position(p, tiles_x) == (px // 64, py // 64))
+    x0, y0 = (px // 64) * 64, (py // 64) * 64
+    win = (x0, y0, x0 + 64, min(H, y0 + 64))
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    opc["frame"] = frame
+    want = O.render(default_scene_arrays, O.pc_bytes(opc), W, H, window=win)
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays); r.resize(W, H)
+        r.set_option(R.RT_OPT_TILE_SIZE, 64); r.set_option(R.RT_OPT_TILE_WORLD, tiles_x * tiles_y); r.set_option(R.RT_OPT_TILE_RANK, pos)
+        for pipeline, traversal in ((0, 0), (3, 0), (1, 0), (2, 0), (4, 0), (3, 1)):
+            r.set_option(R.RT_OPT_PIPELINE, pipeline); r.set_option(R.RT_OPT_TRAVERSAL, traversal)
+            r.clear_accumulation()
+            r.render_frames(to_pc(R, opc), frame, 1, 1) if pipeline != 3 else r.render_frames(to_pc(R, opc), frame - 1, 1, 2)
+            acc = r.read_image(R.RT_IMAGE_ACCUM)
+            if pipeline == 3:
+                opc["frame"] = frame - 1
+                both = O.render(default_scene_arrays, O.pc_bytes(opc), W, H, window=win)
+                opc["frame"] = frame
+                both = O.render(default_scene_arrays, O.pc_bytes(opc), W, H, accum=both["accum"], window=win)
+                ref = both["accum"]
+            else:
+                ref = want["accum"]
+            got, exp = acc[win[1]:win[3], win[0]:win[2]], ref[win[1]:win[3], win[0]:win[2]]
+            if traversal == 0:
+                assert np.array_equal(bits(got), bits(exp)), (pipeline, traversal)
+            else:
+                assert np.mean(np.all(bits(got) == bits(exp), axis=-1)) > 0.999
+            assert not acc[:y0].any() and np.isfinite(got).all()
+    finally:
+        r.close()

@@ -201,3 +201,45 @@ def test_oracle_properties(default_scene_arrays):
     c = O.render(default_scene_arrays, pb, W, H)
     assert np.all(c["out"][..., 3] == 1)
     np.testing.assert_array_equal(c["out"][..., :3], np.sqrt(np.maximum(a["accum"][..., :3], 0), dtype=np.float32))
+
+
+def test_rejection_loop_that_never_accepts_is_cut_off():
+    """Random.glsl:68-78 loops until a vector in the unit ball is drawn; the generator is a fixed
+    permutation of the 32-bit states, and the state the Lambert branch starts from at 3840x2160, frame
+    1010, pixel (3563, 2062), sample 0 sits on a cycle whose draws are all rejected (found by enumerating
+    frames 0..1023 of that size; an independent Python model of the generator confirms the cycle here).
+    The reference shader would spin for ever; the oracle and the kernels return the zero vector after
+    65 536 rounds."""
+    def wang(s):
+        s = ((s ^ 61) ^ (s >> 16)) & M
+        s = (s * 9) & M
+        s = (s ^ (s >> 4)) & M
+        s = (s * 0x27d4eb2d) & M
+        return (s ^ (s >> 15)) & M
+    M = 0xFFFFFFFF
+    s0 = O.seed_from_coords(3563, 2062, 1010, 0)
+    state = wang((s0 + 1) & M)                     # after MaterialScatter's scatterOrReflect draw
+    assert O.rng_draw(s0)[0] == state
+    # the python model: RandomUnitVector's loop from that state revisits a state within a few rounds without accepting
+    s = (state + 1) & M
+    seen = set()
+    for _ in range(64):
+        s = (s + 1) & M
+        start = s
+        v = []
+        for _ in range(3):
+            s = wang((s + 1) & M)
+            r = np.float32(s % 10000) / np.float32(10000.0)
+            v.append(np.float32(-1.0) * (np.float32(1.0) - r) + np.float32(1.0) * r)
+        length = np.sqrt(np.float32(v[0] * v[0] + v[1] * v[1]) + v[2] * v[2], dtype=np.float32)
+        lensq = np.float32(length * length)
+        assert not (0.0 < lensq <= 1.0)
+        if start in seen:
+            break
+        seen.add(start)
+    else:
+        raise AssertionError("no cycle found")
+    assert O.random_unit_vector(state) == (0.0, 0.0, 0.0)
+    # an ordinary state gives a unit vector
+    x, y, z = O.random_unit_vector(O.seed_from_coords(10, 20, 3, 0))
+    assert abs(x * x + y * y + z * z - 1.0) < 1e-6
