@@ -924,8 +924,11 @@ __device__ __forceinline__ int wave_sum(int v)
 // main(), raytrace.comp:857-875. One 64-lane block renders one 8x8 pixel tile.
 // statsOnly != 0: write no image, only report the work counters: 1 = added to *counters, 2 = every
 // wave stores its own record at counters[blockIdx.x] (the caller sums them).
+#ifndef RT_MEGA_WAVES
+#define RT_MEGA_WAVES 4
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void RT_SYM(rt_megakernel)(DevScene S, rt_push_constants pc, DevLaunch L,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_MEGA_WAVES))) void RT_SYM(rt_megakernel)(DevScene S, rt_push_constants pc, DevLaunch L,
                                                             float4* __restrict__ accum, float4* __restrict__ out,
                                                             DevCounters* counters, int statsOnly)
 {

@@ -95,7 +95,11 @@ __device__ __forceinline__ void team_emit(const TeamPath& tp, int k, bool emit, 
     base = (unsigned)__shfl((int)base, 0, 64);
     if (emit) {
         const unsigned rank = (unsigned)__popcll(m & ((1ull << tp.lane) - 1ull));
-        __hip_atomic_store(&tp.sh.ring[(base + rank) & (RT_TEAM_RING - 1)], first + tp.lane, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int* entry = &tp.sh.ring[(base + rank) & (RT_TEAM_RING - 1)];
+        // The entry of one lap ago was claimed long since (fewer jobs are in flight than the ring has
+        // entries, and claims go in ring order); its walker may be about to clear it, though.
+        while (__hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != RT_TEAM_EMPTY) __builtin_amdgcn_s_sleep(1);
+        __hip_atomic_store(entry, first + tp.lane, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -387,7 +391,6 @@ __device__ __forceinline__ void team_walker(const DevScene& S, const TeamShared&
 {
     const float tMin = 0.001f;
     int slot = -1;             // the job this lane works on (path wave * 64 + lane), -1: none
-    int resv = -1;             // ring position this lane has reserved and not yet seen filled
     unsigned meta = 0;
     unsigned long long mask = 0;
     V3 winv = mk(1.0f, 1.0f, 1.0f);
@@ -403,34 +406,48 @@ __device__ __forceinline__ void team_walker(const DevScene& S, const TeamShared&
     const unsigned long long dStart = __builtin_amdgcn_s_memtime();
 #endif
     for (;;) {
-        // ---- refill, only when enough lanes are free (or nothing is being walked): free lanes reserve the
-        // next ring positions with one atomic for the wave and look whether theirs is filled ----
+        // ---- refill, only when enough lanes are free (or nothing is being walked): the wave claims ring
+        // positions that the path waves have already announced (never ahead of the tail: a position
+        // claimed early and read late could be overwritten a lap later), at most one per free lane ----
         const int walking = __popcll(__ballot(slot >= 0));
         if (walking == 0 || walking <= 64 - refillMin) {
-            const unsigned long long want = __ballot(slot < 0 && resv < 0);
-            if (want != 0) {
-                unsigned base = 0;
-                if (lane == 0) base = __hip_atomic_fetch_add(&sh.ctrl[0], (unsigned)__popcll(want), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                base = (unsigned)__shfl((int)base, 0, 64);
-                if (slot < 0 && resv < 0) resv = (int)((base + (unsigned)__popcll(want & ((1ull << lane) - 1ull))) & 0x7fffffffu);
-            }
-            if (slot < 0) {
-                int* entry = &sh.ring[(unsigned)resv & (RT_TEAM_RING - 1)];
-                const int v = __hip_atomic_load(entry, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (v >= 0) {
-                    __hip_atomic_store(entry, RT_TEAM_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    slot = v;
-                    resv = -1;
-                    const float* in = sh.in + (size_t)(v >> 6) * RT_TEAM_IN * 64 + (v & 63);   // v >> 6 = path wave * RT_TEAM_SLOTS + slot
-                    t.rayO = mk(in[0 * 64], in[1 * 64], in[2 * 64]);
-                    t.dirN = mk(in[3 * 64], in[4 * 64], in[5 * 64]);
-                    t.best.closest = in[6 * 64];
-                    t.best.object = -1; t.best.tri = 0; t.best.tLocal = 0.0f; t.best.u = 0.0f; t.best.v = 0.0f;
-                    meta = __float_as_uint(in[7 * 64]);
-                    mask = (unsigned long long)__float_as_uint(in[8 * 64]) | ((unsigned long long)__float_as_uint(in[9 * 64]) << 32);
-                    parW = lean_inverse(t.dirN, winv);
-                    t.cur = RT_TEAM_NEXT;
+            const unsigned long long want = __ballot(slot < 0);
+            unsigned base = 0, got = 0;
+            if (lane == 0) {
+                const unsigned n = (unsigned)__popcll(want);
+                for (;;) {
+                    unsigned h = __hip_atomic_load(&sh.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned tl = __hip_atomic_load(&sh.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned avail = tl - h;     // the tail is read after the head and both only grow
+                    got = n < avail ? n : avail;
+                    if (got == 0) break;
+                    if (__hip_atomic_compare_exchange_strong(&sh.ctrl[0], &h, h + got, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        base = h;
+                        break;
+                    }
                 }
+            }
+            base = (unsigned)__shfl((int)base, 0, 64);
+            got = (unsigned)__shfl((int)got, 0, 64);
+            if (slot < 0 && (unsigned)__popcll(want & ((1ull << lane) - 1ull)) < got) {
+                int* entry = &sh.ring[(base + (unsigned)__popcll(want & ((1ull << lane) - 1ull))) & (RT_TEAM_RING - 1)];
+                // announced, so its path wave is writing it at this moment if it is not there yet
+                int v = __hip_atomic_load(entry, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (v < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    v = __hip_atomic_load(entry, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                __hip_atomic_store(entry, RT_TEAM_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                slot = v;
+                const float* in = sh.in + (size_t)(v >> 6) * RT_TEAM_IN * 64 + (v & 63);   // v >> 6 = path wave * RT_TEAM_SLOTS + slot
+                t.rayO = mk(in[0 * 64], in[1 * 64], in[2 * 64]);
+                t.dirN = mk(in[3 * 64], in[4 * 64], in[5 * 64]);
+                t.best.closest = in[6 * 64];
+                t.best.object = -1; t.best.tri = 0; t.best.tLocal = 0.0f; t.best.u = 0.0f; t.best.v = 0.0f;
+                meta = __float_as_uint(in[7 * 64]);
+                mask = (unsigned long long)__float_as_uint(in[8 * 64]) | ((unsigned long long)__float_as_uint(in[9 * 64]) << 32);
+                parW = lean_inverse(t.dirN, winv);
+                t.cur = RT_TEAM_NEXT;
             }
 #ifdef RT_SECTION_TIMERS
             dJobs += __popcll(__ballot(slot >= 0)) - walking;
