@@ -296,7 +296,12 @@ def main():
         alg_tflops = flops_per_launch / (launch_ms * 1e-3) / 1e12
         traffic = measured_traffic(kernel, args.config, args.traversal, group)
         scene_bytes = sum(a.nbytes for a in arrays)
-        cache_resident = scene_bytes < 32 * 2 ** 20       # the 18 arrays fit the aggregate L2 (8 x 4 MiB)
+        # HBM is the bound only when the measured traffic says so (half the peak or more); without a measurement,
+        # when the scene cannot sit in the caches (aggregate L2 8 x 4 MiB, 256 MiB memory-side cache behind it).
+        # Measured: configs 1-3 move 0.3 TB/s, the 198 MB scene of config 4 0.47 TB/s - every record fetch is a
+        # dependent access served by a cache, so all of them are bound by issue and latency.
+        traffic_rate = None if traffic is None else traffic / (launch_ms * 1e-3) / 1e9
+        cache_resident = (traffic_rate < 0.5 * HBM_PEAK_GBPS) if traffic_rate is not None else (scene_bytes < 256 * 2 ** 20)
         spp_total = frames_rank * (world if not tile_split else 1)
         out = {
             "metric": "Mrays/s", "value": total_rays * args.steps / dt / 1e6, "unit": "Mrays/s",
@@ -313,8 +318,8 @@ def main():
             "rays_per_step": total_rays,
             "rays_counted": "exact (counting kernel over every frame of the step)" if len(counted) == len(my_frames) else
                             "counting kernel over %d evenly spaced frames of %d, scaled" % (len(counted), len(my_frames)),
-            # The scene of configs 1 and 3 (1.2 MB) and of config 2 (15 MB) is served by the caches: the bound is
-            # vector-ALU issue and the latency of dependent record fetches, not HBM. `frac` is the achieved share of
+            # Served by the caches: the bound is vector-ALU issue and the latency of dependent record fetches, not
+            # HBM. `frac` is the achieved share of
             # the FP32 vector peak in algorithmic flops (21 per box test, 45 per triangle test of the REFERENCE
             # traversal); the algorithmic byte rate and the measured HBM traffic are given beside it.
             "roofline": {"bound": "valu+latency" if cache_resident else "hbm",
@@ -323,7 +328,7 @@ def main():
                          "unit": "TFLOP/s" if cache_resident else "GB/s",
                          "frac": alg_tflops / VALU_PEAK_TFLOPS if cache_resident else alg_gbps / HBM_PEAK_GBPS,
                          "traffic": traffic,
-                         "traffic_gbps": None if traffic is None else traffic / (launch_ms * 1e-3) / 1e9,
+                         "traffic_gbps": traffic_rate,
                          "kernel": kernel, "launch_ms": launch_ms, "frames_per_launch": group, "launches_per_step": launches,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_flops_per_launch": flops_per_launch,
                          "scene_bytes": scene_bytes,

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+# RT_AMD_LIBRARY: another build of the same library (a diagnostic or experimental one)
+LIB_PATH = os.environ.get("RT_AMD_LIBRARY") or os.path.join(_HERE, "librt_amd.so")
 MODELS_DIR = os.path.join(os.path.dirname(_HERE), "assets", "models")
 
 RT_IMAGE_DRAW, RT_IMAGE_ACCUM = 0, 1

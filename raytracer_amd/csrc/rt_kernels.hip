@@ -751,7 +751,8 @@ __device__ __forceinline__ void best_reset(Best& b, float tMax)
 
 // GetHit for two rays per lane (see above). onA / onB: the lane has such a ray. ANYHIT: shadow rays,
 // leaf parents first, a ray stops at its first accepted hit.
-template <bool ANYHIT>
+// NF: the scene holds rebuilt trees (DevScene::nearFirstBase set); false compiles the near-first handling out.
+template <bool ANYHIT, bool NF>
 __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V3 oA, V3 dA, bool onA, Best& bA, V3 oB, V3 dB, bool onB,
                                            Best& bB, float tMin, float tMax, uint2* stack)
 {
@@ -760,7 +761,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
     V3 winvA, winvB;
     const bool parWA = lean_inverse(dA, winvA) && onA, parWB = lean_inverse(dB, winvB) && onB;
     const bool permute = ANYHIT && parentCount == S.objectCount;
-    const bool tightScene = S.nearFirstBase != 0x7fffffff;   // the near-first scene: boxes are only culls
+    const bool tightScene = NF;   // the near-first scene: boxes are only culls
     for (int pos = 0; pos < parentCount; ++pos) {
         const int i = permute ? S.anyOrder[pos] : pos;
         const DevObject* ob = S.objects + i;   // wave-uniform address
@@ -801,7 +802,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
         V3 linv = ld;
         bool parL = lean_inverse(ld, linv);
         int cur = root, sp = 0;
-        const bool nearFirst = root >= S.nearFirstBase;   // wave-uniform: a rebuilt tree, nearer child first
+        const bool nearFirst = NF && root >= S.nearFirstBase;   // wave-uniform: a rebuilt tree, nearer child first
         for (;;) {
             while ((unsigned)cur < (unsigned)RT_NONE) {
                 NodeVisit nv;
@@ -1066,6 +1067,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_MEGA_WAVE
 #ifndef RT_PAIR_WAVES
 #define RT_PAIR_WAVES 4
 #endif
+template <bool NF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVES))) void RT_SYM(rt_pairkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
                                                             float4* __restrict__ accum, float4* __restrict__ out)
 {
@@ -1113,12 +1115,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             if (!(P[0].alive || P[1].alive)) break;
             const V3 dirA = normalize3(P[0].d), dirB = normalize3(P[1].d);
             Best bA, bB;
-            trace_pair<false>(S, pc.parentBVHCount, P[0].o, dirA, P[0].alive, bA, P[1].o, dirB, P[1].alive, bB, 0.001f, 1e20f, stack);
+            trace_pair<false, NF>(S, pc.parentBVHCount, P[0].o, dirA, P[0].alive, bA, P[1].o, dirB, P[1].alive, bB, 0.001f, 1e20f, stack);
             // (the seed of a sample is recomputed where it is needed rather than carried through the walks)
             pair_shade(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, y, n, rpp));
             pair_shade(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, y, n + 1, rpp));
             if (P[0].shadow || P[1].shadow) {
-                trace_pair<true>(S, pc.parentBVHCount, P[0].so, sunDirN, P[0].shadow, bA, P[1].so, sunDirN, P[1].shadow, bB, 0.001f, 1e20f, stack);
+                trace_pair<true, NF>(S, pc.parentBVHCount, P[0].so, sunDirN, P[0].shadow, bA, P[1].so, sunDirN, P[1].shadow, bB, 0.001f, 1e20f, stack);
                 if (P[0].shadow && bA.object < 0) P[0].result = P[0].result + P[0].sun;
                 if (P[1].shadow && bB.object < 0) P[1].result = P[1].result + P[1].sun;
             }
@@ -2271,7 +2273,11 @@ extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_p
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
-    hipLaunchKernelGGL(RT_SYM(rt_pairkernel), dim3((unsigned)blocks), dim3(64), lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    // two builds of one kernel: <true> knows rebuilt trees (near-first traversal), <false> has that handling compiled out
+    if (S->nearFirstBase != 0x7fffffff)
+        hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<true>, dim3((unsigned)blocks), dim3(64), lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else
+        hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<false>, dim3((unsigned)blocks), dim3(64), lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
     return hipGetLastError();
 }
 
