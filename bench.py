@@ -278,6 +278,39 @@ def main():
     if world == 1 and args.compare:
         other = timed(1 - args.traversal)
         r.set_option(R.RT_OPT_TRAVERSAL, args.traversal)
+
+    exchange = None
+    if distributed:
+        # the exchange step alone, after the timed region (it is inside `value` as part of every step): best of three
+        dog.arm(args.stage_timeout, "exchange timing")
+        image_bytes = W * H * 16
+        best = float("inf")
+        if tile_split:
+            target.set_tiles(rank, world, 64)
+        for _ in range(3):
+            fence()
+            t0 = time.perf_counter()
+            with target.stream_context():
+                if tile_split:
+                    D.exchange_tile_split(target, 64)
+                else:
+                    D.exchange_sample_split(target)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        if tile_split:
+            target.set_tiles(0, 1, 64)
+        tex = torch.tensor([best], dtype=torch.float64)
+        if args.backend == "nccl":
+            tex = tex.to(dev); dist.all_reduce(tex, op=dist.ReduceOp.MAX)
+        else:
+            dist.all_reduce(tex, op=dist.ReduceOp.MAX)
+        ex_s = float(tex.item())
+        # bytes a GPU sends in a ring schedule: all-reduce 2(N-1)/N of the image, all-gather (N-1)/N of its share of two images x N
+        sent = (2.0 * (world - 1) / world * image_bytes) if not tile_split else ((world - 1) / world * 2.0 * image_bytes)
+        exchange = {"kind": "all-gather of owned tiles (accumulation + draw image)" if tile_split else "all-reduce (sum) of the accumulation image",
+                    "ms": ex_s * 1e3, "bytes_sent_per_gpu": sent, "gbps_per_gpu": sent / ex_s / 1e9,
+                    "note": "ring schedule assumed for the byte count; one xGMI link carries about 153 GB/s"}
+        mark("exchange timed")
     dog.arm(args.stage_timeout, "reporting")
 
     if rank == 0:
@@ -337,6 +370,8 @@ def main():
                                          "a work rate, not bytes that cross the HBM interface"},
                          "valu": {"achieved_tflops": alg_tflops, "peak_tflops": VALU_PEAK_TFLOPS, "frac": alg_tflops / VALU_PEAK_TFLOPS}},
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         if other is not None:
             odt, okms = other
             out["other_flavour"] = {"flavour": "%s traversal, %s arithmetic" % (names[1 - args.traversal], "FMA-contracted" if args.fast else "strict binary32"),

@@ -151,6 +151,24 @@ def _gather_tiles_torch(target, rank, world, tile_size, group):
                 draw[y0:y0 + h, x0:x0 + w] = parts[r][k, 1, :h, :w]
 
 
+def exchange_sample_split(target, group=None):
+    """The exchange step of a sample split alone: the accumulation images of all ranks summed in place."""
+    if getattr(target, "native_comm", False):
+        target.merge_accum()
+    else:
+        _all_reduce_sum(target, target.accum, group)
+
+
+def exchange_tile_split(target, tile_size=64, group=None):
+    """The exchange step of a tile split alone: every rank's own tiles of both images to every other rank.
+    The target's tile options must name this rank's share (render_tile_split sets them)."""
+    rank, world = _world(group)
+    if getattr(target, "native_comm", False):
+        target.gather_tiles()
+    else:
+        _gather_tiles_torch(target, rank, world, tile_size, group)
+
+
 def render_sample_split(target, frames_per_rank, group=None, always_reduce=False):
     """Every rank ends with the merged accumulation image (frames_per_rank * world samples per
     pixel) and the resolved draw image. Returns the total number of frames. always_reduce: issue
@@ -161,10 +179,7 @@ def render_sample_split(target, frames_per_rank, group=None, always_reduce=False
         target.clear()
         target.render_frames(rank, world, frames_per_rank)
         if world > 1 or always_reduce:
-            if getattr(target, "native_comm", False):
-                target.merge_accum()
-            else:
-                _all_reduce_sum(target, target.accum, group)
+            exchange_sample_split(target, group)
         total = frames_per_rank * world
         target.resolve(total)
     return total
@@ -179,10 +194,7 @@ def render_tile_split(target, frames, tile_size=64, group=None, always_reduce=Fa
         target.clear()
         target.render_frames(0, 1, frames)
         if world > 1 or always_reduce:
-            if getattr(target, "native_comm", False):
-                target.gather_tiles()
-            else:
-                _gather_tiles_torch(target, rank, world, tile_size, group)
+            exchange_tile_split(target, tile_size, group)
         target.set_tiles(0, 1, tile_size)
     return frames
 
@@ -202,6 +214,9 @@ class GpuTarget:
         self.draw = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
         self.accum = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
         self.native_comm = False
+        # allocated on the current stream, used on the target's own from here on
+        self.draw.record_stream(self.stream)
+        self.accum.record_stream(self.stream)
         torch.cuda.synchronize(self.device)
         renderer.bind_images(self.draw.data_ptr(), self.accum.data_ptr(), width, height)
         renderer.set_stream(self.stream.cuda_stream)
