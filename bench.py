@@ -202,7 +202,21 @@ def main():
     target = D.GpuTarget(r, pc, W, H, dev)      # images are torch tensors, kernels run on a torch stream the target owns
     native = distributed and (args.comm == "native" or (args.comm == "auto" and args.backend == "nccl"))
     if native:
-        target.init_comm()
+        # the library's own communicator; should it fail to come up on any rank, every rank falls back to
+        # torch.distributed's collectives on the same backend (RCCL either way), and the bench line says which
+        try:
+            target.init_comm()
+            up = 1.0
+        except R.RtError as exc:
+            sys.stderr.write("[rank %d] rt_comm_init failed (%s): using torch.distributed's collectives\n" % (rank, exc))
+            up = 0.0
+        flag = torch.tensor([up], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            if target.native_comm:
+                r.comm_destroy()
+                target.native_comm = False
+            native = False
     mark("scene uploaded, communicator %s" % ("native" if native else "torch" if distributed else "none"))
 
     # untimed counting pass: GetHit calls and the shader's node/triangle test counters of this rank's
