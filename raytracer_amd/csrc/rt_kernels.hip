@@ -749,6 +749,134 @@ __device__ __forceinline__ void best_reset(Best& b, float tMax)
     b.closest = tMax; b.object = -1; b.tri = 0; b.u = 0.0f; b.v = 0.0f; b.tLocal = 0.0f;
 }
 
+// ---------------------------------------------------------------------------------
+// A run of consecutive BVH parents, lane by lane. The object loop of GetHit is wave-uniform: the
+// whole wave enters parent after parent, and inside each one only the lanes whose ray meets that
+// parent's box have work (a dozen of 64 on the scenes measured), so a scene with many BVH parents
+// is walked as many sparse walks one after the other. A ray, however, only has to see ITS parents
+// in order (its closest hit is its own): here every lane goes through the parents of the run that
+// its rays can enter, one ray after the other, parent after parent in the run's order, each parent's
+// box tested against the ray's closest hit of that moment exactly as the wave-uniform loop does.
+// Different lanes are inside different parents at the same time; object records come through
+// per-lane (vector) loads instead of scalar ones. Same tests in the same order per ray: same bits.
+#ifndef RT_RUN_MIN
+#define RT_RUN_MIN 2        /* consecutive BVH parents from which on a run is walked lane by lane */
+#endif
+
+template <bool ANYHIT, bool NF>
+__device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, int pos0, int count, V3 oA, V3 dA, V3 winvA, bool liveA, Best& bA,
+                                              V3 oB, V3 dB, V3 winvB, bool liveB, Best& bB, bool anyPar, float tMin, uint2* stack)
+{
+    // which parents of the run a ray can enter at all (a parent whose box does not reach inside the
+    // closest hit now will not later either: closest hits only come closer)
+    unsigned long long mA = 0, mB = 0;
+    for (int k = 0; k < count; ++k) {
+        const int j = permute ? S.anyOrder[pos0 + k] : pos0 + k;
+        const DevObject* o2 = S.objects + j;     // wave-uniform address
+        const V3 bmn = ld3(o2->bmin), bmx = ld3(o2->bmax);
+        float E;
+        if (liveA && (anyPar ? lean_box<true>(oA, winvA, bmn, bmx, tMin, E) : lean_box<false>(oA, winvA, bmn, bmx, tMin, E)) && (bA.closest > E))
+            mA |= 1ull << k;
+        if (liveB && (anyPar ? lean_box<true>(oB, winvB, bmn, bmx, tMin, E) : lean_box<false>(oB, winvB, bmn, bmx, tMin, E)) && (bB.closest > E))
+            mB |= 1ull << k;
+    }
+    if (!__any((mA | mB) != 0)) return;
+
+    bool active = (mA | mB) != 0;
+    bool second = false;
+    unsigned long long m = mA;
+    V3 org = oA, dirN = dA, winv = winvA;
+    Best bw = bA;
+    V3 lo = oA, ld = dA, linv = dA;
+    bool parL = false, nearFirst = false;
+    int cur = RT_NONE, sp = 0, obj = 0;
+    const DevObject* ob = S.objects;
+    for (;;) {
+        if (active && cur == RT_NONE) {
+            // the ray's next parent; after its last one the lane's other ray; after that the lane is done
+            if (ANYHIT && bw.object >= 0) m = 0;
+            if (m == 0 && !second) {
+                bA = bw;
+                second = true;
+                m = mB;
+                org = oB; dirN = dB; winv = winvB;
+                bw = bB;
+            }
+            if (m == 0) {
+                bB = bw;
+                active = false;
+            } else {
+                const int k = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                obj = permute ? S.anyOrder[pos0 + k] : pos0 + k;
+                ob = S.objects + obj;
+                const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+                float E;
+                bool ok = (anyPar ? lean_box<true>(org, winv, bmn, bmx, tMin, E) : lean_box<false>(org, winv, bmn, bmx, tMin, E)) && (bw.closest > E);
+                if (!NF && ok) ok = !(distance_to_aabb(org, bmn, bmx) > bw.closest);
+                if (ok) {
+                    lo = xform(ob->inv, org, 1.0f);
+                    ld = normalize3(xform(ob->inv, dirN, 0.0f));
+                    linv = ld;
+                    parL = lean_inverse(ld, linv);
+                    cur = ob->root;
+                    nearFirst = NF && cur >= S.nearFirstBase;
+                    sp = 0;
+                }
+            }
+        }
+        if (!__any(active)) break;
+        if (cur != RT_NONE) {
+            while ((unsigned)cur < (unsigned)RT_NONE) {
+                NodeVisit nv;
+                visit_node(S, cur, lo, linv, __any(parL), tMin, nv);
+                int2 refs = nv.refs;
+                const bool goF = refs.x > RT_REF_LIVE_MIN && nv.okF && (bw.closest > nv.EF);
+                bool canS = refs.y > RT_REF_LIVE_MIN && nv.okS;
+                if (NF && nearFirst) {
+                    canS = canS && (bw.closest > nv.ES);
+                    if (goF && canS && nv.ES < nv.EF) {
+                        const int r = refs.x; refs.x = refs.y; refs.y = r;
+                        const float e = nv.EF; nv.EF = nv.ES; nv.ES = e;
+                    }
+                }
+                if (goF) {
+                    if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(nv.ES)); ++sp; }
+                    cur = refs.x;
+                } else if (canS && (bw.closest > nv.ES)) {
+                    cur = refs.y;
+                } else {
+                    cur = RT_NONE;
+                    while (sp > 0) {
+                        --sp;
+                        const uint2 e = stack[sp * 64];
+                        if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                    }
+                }
+            }
+            if (cur != RT_NONE) {
+                int k = ~cur;
+                bool stop = false;
+                for (;;) {
+                    const float4* tp = reinterpret_cast<const float4*>(S.tris + k);
+                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    const int remaining = __float_as_int(t0.w);
+                    if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, obj, bw) && ANYHIT) { stop = true; break; }
+                    if (remaining <= 1) break;
+                    ++k;
+                }
+                cur = RT_NONE;
+                if (stop) sp = 0;
+                while (sp > 0) {
+                    --sp;
+                    const uint2 e = stack[sp * 64];
+                    if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                }
+            }
+        }
+    }
+}
+
 // GetHit for two rays per lane (see above). onA / onB: the lane has such a ray. ANYHIT: shadow rays,
 // leaf parents first, a ray stops at its first accepted hit.
 // NF: the scene holds rebuilt trees (DevScene::nearFirstBase set); false compiles the near-first handling out.
@@ -765,9 +893,19 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
     for (int pos = 0; pos < parentCount; ++pos) {
         const int i = permute ? S.anyOrder[pos] : pos;
         const DevObject* ob = S.objects + i;   // wave-uniform address
-        const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
         const bool liveA = onA && !(ANYHIT && bA.object >= 0), liveB = onB && !(ANYHIT && bB.object >= 0);
         if (ANYHIT && !__any(liveA || liveB)) break;
+        if (ob->root >= 0) {
+            // consecutive BVH parents (up to 64): RT_RUN_MIN or more are walked lane by lane
+            int count = 1;
+            while (count < 64 && pos + count < parentCount && S.objects[permute ? S.anyOrder[pos + count] : pos + count].root >= 0) ++count;
+            if (count >= RT_RUN_MIN) {
+                walk_run_pair<ANYHIT, NF>(S, permute, pos, count, oA, dA, winvA, liveA, bA, oB, dB, winvB, liveB, bB, __any(parWA || parWB), tMin, stack);
+                pos += count - 1;
+                continue;
+            }
+        }
+        const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
         float E;
         bool okA = liveA && (__any(parWA) ? lean_box<true>(oA, winvA, bmn, bmx, tMin, E) : lean_box<false>(oA, winvA, bmn, bmx, tMin, E)) &&
                    (bA.closest > E);
