@@ -379,6 +379,103 @@ __device__ __forceinline__ bool triangle_hit(float4 t0, float4 t1, float4 t2, V3
 
 #define RT_NONE 0x7fffffff
 
+#ifndef RT_RUN_MIN
+#define RT_RUN_MIN 2        /* consecutive BVH parents from which on a run is walked lane by lane */
+#endif
+
+// A run of consecutive BVH parents gone through lane by lane (see walk_run_pair below for the idea):
+// every lane visits the parents of the run that its ray can enter, in the run's order, each parent's
+// box tested against the ray's closest hit of that moment as the wave-uniform loop of trace() does;
+// different lanes are inside different parents at the same time. One ray per lane.
+template <bool ANYHIT>
+__device__ __forceinline__ void walk_run_single(const DevScene& S, bool permute, int pos0, int count, bool tightScene, V3 org, V3 dirN, V3 winv,
+                                                bool anyPar, Best& best, float tMin, uint2* stack)
+{
+    unsigned long long m = 0;
+    for (int k = 0; k < count; ++k) {
+        const int j = permute ? S.anyOrder[pos0 + k] : pos0 + k;
+        const DevObject* o2 = S.objects + j;     // wave-uniform address
+        const V3 bmn = ld3(o2->bmin), bmx = ld3(o2->bmax);
+        float E;
+        if ((anyPar ? lean_box<true>(org, winv, bmn, bmx, tMin, E) : lean_box<false>(org, winv, bmn, bmx, tMin, E)) && (best.closest > E))
+            m |= 1ull << k;
+    }
+    V3 lo = org, ld = dirN, linv = dirN;
+    bool parL = false, nearFirst = false;
+    int cur = RT_NONE, sp = 0, obj = 0;
+    const DevObject* ob = S.objects;
+    for (;;) {
+        if (cur == RT_NONE && m != 0) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            obj = permute ? S.anyOrder[pos0 + k] : pos0 + k;
+            ob = S.objects + obj;
+            const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+            float E;
+            bool ok = (anyPar ? lean_box<true>(org, winv, bmn, bmx, tMin, E) : lean_box<false>(org, winv, bmn, bmx, tMin, E)) && (best.closest > E);
+            if (ok && !tightScene) ok = !(distance_to_aabb(org, bmn, bmx) > best.closest);
+            if (ok) {
+                lo = xform(ob->inv, org, 1.0f);
+                ld = normalize3(xform(ob->inv, dirN, 0.0f));
+                linv = ld;
+                parL = lean_inverse(ld, linv);
+                cur = ob->root;
+                nearFirst = cur >= S.nearFirstBase;
+                sp = 0;
+            }
+        }
+        if (!__any(cur != RT_NONE || m != 0)) break;
+        if (cur != RT_NONE) {
+            while ((unsigned)cur < (unsigned)RT_NONE) {
+                NodeVisit nv;
+                visit_node(S, cur, lo, linv, __any(parL), tMin, nv);
+                int2 refs = nv.refs;
+                const bool goF = refs.x > RT_REF_LIVE_MIN && nv.okF && (best.closest > nv.EF);
+                bool canS = refs.y > RT_REF_LIVE_MIN && nv.okS;
+                if (nearFirst) {
+                    canS = canS && (best.closest > nv.ES);
+                    if (goF && canS && nv.ES < nv.EF) {
+                        const int r = refs.x; refs.x = refs.y; refs.y = r;
+                        const float e = nv.EF; nv.EF = nv.ES; nv.ES = e;
+                    }
+                }
+                if (goF) {
+                    if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(nv.ES)); ++sp; }
+                    cur = refs.x;
+                } else if (canS && (best.closest > nv.ES)) {
+                    cur = refs.y;
+                } else {
+                    cur = RT_NONE;
+                    while (sp > 0) {
+                        --sp;
+                        const uint2 e = stack[sp * 64];
+                        if (best.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                    }
+                }
+            }
+            if (cur != RT_NONE) {
+                int k = ~cur;
+                bool stop = false;
+                for (;;) {
+                    const float4* tp = reinterpret_cast<const float4*>(S.tris + k);
+                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    const int remaining = __float_as_int(t0.w);
+                    if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, obj, best) && ANYHIT) { stop = true; break; }
+                    if (remaining <= 1) break;
+                    ++k;
+                }
+                cur = RT_NONE;
+                if (stop) { sp = 0; m = 0; }
+                while (sp > 0) {
+                    --sp;
+                    const uint2 e = stack[sp * 64];
+                    if (best.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                }
+            }
+        }
+    }
+}
+
 // GetHit, raytrace.comp:448-610. dirN must already be normalize(r_in.direction).
 template <bool COUNT, bool ANYHIT>
 __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org, V3 dirN, float tMin, float tMax,
@@ -401,6 +498,17 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
     for (int pos = 0; pos < parentCount; ++pos) {
         const int i = permute ? S.anyOrder[pos] : pos;
         const DevObject* ob = S.objects + i;   // wave-uniform address
+        if (!COUNT && ob->root >= 0) {
+            // consecutive BVH parents (up to 64): RT_RUN_MIN or more are gone through lane by lane
+            int count = 1;
+            while (count < 64 && pos + count < parentCount && S.objects[permute ? S.anyOrder[pos + count] : pos + count].root >= 0) ++count;
+            if (count >= RT_RUN_MIN) {
+                walk_run_single<ANYHIT>(S, permute, pos, count, tightScene, org, dirN, winv, __any(parW), best, tMin, stack);
+                if (ANYHIT && best.object >= 0) return true;
+                pos += count - 1;
+                continue;
+            }
+        }
         if (COUNT) cnt.nodeTests++;
         V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
         float E;
@@ -759,10 +867,6 @@ __device__ __forceinline__ void best_reset(Best& b, float tMax)
 // box tested against the ray's closest hit of that moment exactly as the wave-uniform loop does.
 // Different lanes are inside different parents at the same time; object records come through
 // per-lane (vector) loads instead of scalar ones. Same tests in the same order per ray: same bits.
-#ifndef RT_RUN_MIN
-#define RT_RUN_MIN 2        /* consecutive BVH parents from which on a run is walked lane by lane */
-#endif
-
 template <bool ANYHIT, bool NF>
 __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, int pos0, int count, V3 oA, V3 dA, V3 winvA, bool liveA, Best& bA,
                                               V3 oB, V3 dB, V3 winvB, bool liveB, Best& bB, bool anyPar, float tMin, uint2* stack)
