@@ -874,6 +874,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
     // which parents of the run a ray can enter at all (a parent whose box does not reach inside the
     // closest hit now will not later either: closest hits only come closer)
     unsigned long long mA = 0, mB = 0;
+    RT_SEC_BEGIN(secPre);
     for (int k = 0; k < count; ++k) {
         const int j = permute ? S.anyOrder[pos0 + k] : pos0 + k;
         const DevObject* o2 = S.objects + j;     // wave-uniform address
@@ -884,6 +885,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
         if (liveB && (anyPar ? lean_box<true>(oB, winvB, bmn, bmx, tMin, E) : lean_box<false>(oB, winvB, bmn, bmx, tMin, E)) && (bB.closest > E))
             mB |= 1ull << k;
     }
+    RT_SEC_END(5, secPre);
     if (!__any((mA | mB) != 0)) return;
 
     bool active = (mA | mB) != 0;
@@ -988,6 +990,7 @@ template <bool ANYHIT, bool NF>
 __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V3 oA, V3 dA, bool onA, Best& bA, V3 oB, V3 dB, bool onB,
                                            Best& bB, float tMin, float tMax, uint2* stack)
 {
+    RT_SEC_BEGIN(secTrace);
     best_reset(bA, tMax);
     best_reset(bB, tMax);
     V3 winvA, winvB;
@@ -1004,7 +1007,9 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
             int count = 1;
             while (count < 64 && pos + count < parentCount && S.objects[permute ? S.anyOrder[pos + count] : pos + count].root >= 0) ++count;
             if (count >= RT_RUN_MIN) {
+                RT_SEC_BEGIN(secRun);
                 walk_run_pair<ANYHIT, NF>(S, permute, pos, count, oA, dA, winvA, liveA, bA, oB, dB, winvB, liveB, bB, __any(parWA || parWB), tMin, stack);
+                RT_SEC_END(ANYHIT ? 6 : 3, secRun);
                 pos += count - 1;
                 continue;
             }
@@ -1021,6 +1026,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
         if (!(root > RT_REF_LIVE_MIN) || !__any(okA || okB)) continue;
         if (root < 0) {
             // one leaf (a wall): records through the scalar cache, both rays test them
+            RT_SEC_BEGIN(secWall);
             const V3 loA = xform(ob->inv, oA, 1.0f), ldA = normalize3(xform(ob->inv, dA, 0.0f));
             const V3 loB = xform(ob->inv, oB, 1.0f), ldB = normalize3(xform(ob->inv, dB, 0.0f));
             const float4* tp = reinterpret_cast<const float4*>(S.tris + ~root);
@@ -1031,6 +1037,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
                 if (__float_as_int(t0.w) <= 1) break;
                 tp += 3;
             }
+            RT_SEC_END(ANYHIT ? 7 : 2, secWall);
             continue;
         }
         if (!(okA || okB)) continue;
@@ -1107,6 +1114,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
             }
         }
     }
+    RT_SEC_END(1, secTrace);
 }
 
 // The part of RayColour's loop body between two GetHit calls (raytrace.comp:701-766) for one path:
@@ -1316,6 +1324,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
     extern __shared__ uint2 stackMem[];
     const int lane = threadIdx.x;
     uint2* stack = stackMem + lane;
+#ifdef RT_SECTION_TIMERS
+    if (lane < 8) rt_sec_lds()[lane] = 0;
+#endif
+    RT_SEC_BEGIN(secKernel);
 
     const int wavesX = L.tileSize >> 3;
     const int wavesPerTile = wavesX * wavesX;
@@ -1359,8 +1371,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             Best bA, bB;
             trace_pair<false, NF>(S, pc.parentBVHCount, P[0].o, dirA, P[0].alive, bA, P[1].o, dirB, P[1].alive, bB, 0.001f, 1e20f, stack);
             // (the seed of a sample is recomputed where it is needed rather than carried through the walks)
+            RT_SEC_BEGIN(secShade);
             pair_shade(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, y, n, rpp));
             pair_shade(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, y, n + 1, rpp));
+            RT_SEC_END(4, secShade);
             if (P[0].shadow || P[1].shadow) {
                 trace_pair<true, NF>(S, pc.parentBVHCount, P[0].so, sunDirN, P[0].shadow, bA, P[1].so, sunDirN, P[1].shadow, bB, 0.001f, 1e20f, stack);
                 if (P[0].shadow && bA.object < 0) P[0].result = P[0].result + P[0].sun;
@@ -1388,6 +1402,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
     float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(nc.x, nc.y, nc.z, 1.0f);
     avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
     out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
+#ifdef RT_SECTION_TIMERS
+    if (lane == __ffsll((long long)__ballot(true)) - 1) {
+        unsigned* a = rt_sec_lds();
+        a[0] = (unsigned)__builtin_amdgcn_s_memtime() - secKernel;
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_sectionCycles[k], (unsigned long long)a[k]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------
