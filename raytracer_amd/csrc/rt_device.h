@@ -41,6 +41,8 @@ struct DevObject {
     float   fwd[12];       /* inverse(inverseTransform), same row layout */
 };
 
+static_assert(sizeof(DevObject) == 128, "DevObject: two 16-byte box words and two 3x4 matrices");
+
 struct DevNode {
     float   lo[3][2];           /* lo[axis][c]: box minimum of the child visited first (c = 0) / second (c = 1) */
     float   hi[3][2];           /* box maximum; the two children sit side by side so that one packed f32

@@ -229,3 +229,34 @@ def test_generated_configs_full_size(R, name, tmp_path_factory):
             assert ok >= 0.995, (win, same, ok)
     finally:
         r.close()
+
+
+def test_more_than_64_bvh_parents_in_a_row(R):
+    """70 BVH parents in a row (the lock-step kernels go through runs of BVH parents lane by lane, 64 parents
+    at a time), a wall behind them and a floor: reference order bit-exact on pipelines 3 and 0, near-first
+    within the bars. Unit-scale cubes and spheres walk rebuilt trees, the shrunk icospheres keep theirs."""
+    materials = [scenes.mat((0.6, 0.6, 0.6)), scenes.mat((0.8, 0.3, 0.2)), scenes.mat((0.9, 0.9, 0.9), smoothness=1.0),
+                 scenes.mat((1, 1, 1), ior=1.5)]
+    objects = []
+    for k in range(70):
+        gx, gy = k % 10, k // 10
+        model, scale = (("cube.obj", 1.0), ("smooth_sphere.obj", 1.0), ("icosphere.obj", 0.5))[k % 3]
+        objects.append((model, (-9.0 + 2.0 * gx, 0.6 + 1.6 * gy, -6.0 - 0.7 * (k % 4)), (0, 17 * k, 0), (scale * 0.6,) * 3 if scale != 1.0 else (1.0, 1.0, 1.0), 1 + k % 3))
+    objects.append(("flat_quad.obj", (0, 0, 0), (0, 0, 0), (40, 40, 40), 0))
+    objects.append(("flat_quad.obj", (0, 0, -12), (90, 0, 0), (40, 40, 40), 0))
+    arrays = scenes.build_oracle(materials, objects).bindings()
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(arrays)
+        assert 0 < r.get_option(R.RT_INFO_FAST_OBJECTS) < 70
+        W, H = 240, 136
+        opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 6.0, 9.0), look=(0.0, -0.1, -1.0), fov=70.0, maxBounces=4)
+        want_acc, want_out = oracle(arrays, opc, [0, 1], W, H)
+        for pipeline in (3, 0, 4):
+            acc, out = render(R, r, opc, [0, 1], W, H, 0, pipeline)
+            assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bits(out), bits(want_out)), pipeline
+            acc, out = render(R, r, opc, [0, 1], W, H, 1, pipeline)
+            same, ok = shares(acc, want_acc)
+            assert ok >= 0.995 and same >= 0.99, (pipeline, same, ok)
+    finally:
+        r.close()
