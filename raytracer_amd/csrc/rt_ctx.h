@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -35,7 +36,8 @@ struct rt_ctx {
     // near-first scene built from them on first use (RT_OPT_TRAVERSAL = 1): its own object records
     // (tight world boxes, roots in the rebuilt trees), and record / triangle arrays that hold the
     // rebuilt trees (behind a copy of the reference-order records when some object has to keep those)
-    std::vector<DevObject> hObjects;
+    std::vector<DevObject> hObjects, hFastObjects;     // host copies of the object records (reference scene, near-first twin)
+    float anyOrderSun[3] = { NAN, NAN, NAN };           // sun direction the any-hit order tables are sorted for
     std::vector<DevNode> hNodes;
     std::vector<DevTri> hTris;
     int hStackDepth = 0;

@@ -98,6 +98,7 @@ namespace {
 
 void freeFastScene(rt_ctx* c)
 {
+    c->hFastObjects.clear();
     for (void** p : { &c->dFastObjects, &c->dFastNodes, &c->dFastTris, &c->dFastAnyOrder }) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -310,23 +311,63 @@ int uploadArray(rt_ctx* ctx, void** dst, const void* src, size_t bytes)
     return RT_OK;
 }
 
-// Order in which "any hit" rays visit the objects: leaf parents (a handful of triangles, no walk)
-// before BVH parents; both groups keep their scene order. Layout: anyOrder[P], pad, nextAny[P + 1].
-std::vector<int32_t> orderTables(const std::vector<DevObject>& objects, int32_t& anyFirst, int32_t& leafCount)
+// Order in which "any hit" rays (shadow rays) visit the objects: leaf parents (a handful of triangles, no
+// walk) before BVH parents; inside each group the parents whose box centre lies furthest towards the sun
+// come first (towardsSun = -sunDirection; null or a zero vector: scene order) - what blocks a shadow ray lies
+// between its origin and the sun, and a wave is done with its shadow rays as soon as every one of them is
+// blocked. The order changes no result (a shadow ray only reports whether anything is hit).
+// Layout: anyOrder[P], pad, nextAny[P + 1].
+std::vector<int32_t> orderTables(const std::vector<DevObject>& objects, int32_t& anyFirst, int32_t& leafCount, const float* towardsSun = nullptr)
 {
     const int32_t P = (int32_t)objects.size();
     std::vector<int32_t> anyOrder, tables(2 * (size_t)P + 2, P);
     for (int pass = 0; pass < 2; ++pass)
         for (int32_t i = 0; i < P; ++i)
             if ((objects[i].root >= 0) == (pass == 1)) anyOrder.push_back(i);
+    leafCount = 0;
+    for (int32_t i = 0; i < P; ++i) leafCount += objects[i].root < 0 ? 1 : 0;
+    if (towardsSun && (towardsSun[0] != 0.0f || towardsSun[1] != 0.0f || towardsSun[2] != 0.0f) &&
+        std::isfinite(towardsSun[0]) && std::isfinite(towardsSun[1]) && std::isfinite(towardsSun[2])) {
+        std::vector<float> score((size_t)P);
+        for (int32_t i = 0; i < P; ++i) {
+            const DevObject& o = objects[i];
+            const float v = 0.5f * ((o.bmin[0] + o.bmax[0]) * towardsSun[0] + (o.bmin[1] + o.bmax[1]) * towardsSun[1] +
+                                    (o.bmin[2] + o.bmax[2]) * towardsSun[2]);
+            score[(size_t)i] = std::isfinite(v) ? v : -INFINITY;
+        }
+        auto nearerTheSun = [&](int32_t x, int32_t y) { return score[(size_t)x] > score[(size_t)y]; };
+        std::stable_sort(anyOrder.begin(), anyOrder.begin() + leafCount, nearerTheSun);
+        std::stable_sort(anyOrder.begin() + leafCount, anyOrder.end(), nearerTheSun);
+    }
     for (int32_t p = 0; p < P; ++p) {
         tables[p] = anyOrder[p];                                         // anyOrder
         tables[P + 1 + anyOrder[p]] = p + 1 < P ? anyOrder[p + 1] : P;   // nextAny
     }
     anyFirst = P > 0 ? anyOrder[0] : 0;
-    leafCount = 0;
-    for (int32_t i = 0; i < P; ++i) leafCount += objects[i].root < 0 ? 1 : 0;
     return tables;
+}
+
+// Re-sorts the any-hit order of the uploaded scene (and of its near-first twin, if built) for a new sun
+// direction. The tables keep their size, so they are overwritten in place, on the context's stream, behind
+// the launches that still read the old order.
+int refreshAnyOrder(rt_ctx* ctx, const float sunDirection[3])
+{
+    if (!ctx->haveScene) return RT_OK;
+    if (std::memcmp(ctx->anyOrderSun, sunDirection, sizeof(ctx->anyOrderSun)) == 0) return RT_OK;
+    const float towards[3] = { -sunDirection[0], -sunDirection[1], -sunDirection[2] };
+    for (int which = 0; which < 2; ++which) {
+        const std::vector<DevObject>& objects = which ? ctx->hFastObjects : ctx->hObjects;
+        void* dst = which ? ctx->dFastAnyOrder : ctx->dAnyOrder;
+        DevScene& scene = which ? ctx->fastScene : ctx->scene;
+        if (!dst || objects.empty()) continue;
+        int32_t anyFirst = 0, leafCount = 0;
+        const std::vector<int32_t> tables = orderTables(objects, anyFirst, leafCount, towards);
+        RT_HIP(ctx, hipMemcpyAsync(dst, tables.data(), tables.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the staging vector dies here
+        scene.anyFirst = anyFirst;
+    }
+    std::memcpy(ctx->anyOrderSun, sunDirection, sizeof(ctx->anyOrderSun));
+    return RT_OK;
 }
 
 // Largest singular value of the 3x3 linear part of a row-major 3x4 matrix: the square root of the
@@ -456,6 +497,8 @@ int ensureFastScene(rt_ctx* ctx)
     if ((rc = uploadArray(ctx, &ctx->dFastTris, tris.data(), tris.size() * sizeof(DevTri))) != RT_OK) return rc;
     if ((rc = uploadArray(ctx, &ctx->dFastAnyOrder, tables.data(), tables.size() * sizeof(int32_t))) != RT_OK) return rc;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die at return
+    ctx->hFastObjects = objects;
+    std::memset(ctx->anyOrderSun, 0xff, sizeof(ctx->anyOrderSun));     // both tables are sorted again at the next launch
     DevScene f = ctx->scene;
     f.objects = static_cast<const DevObject*>(ctx->dFastObjects);
     f.nodes = static_cast<const DevNode*>(ctx->dFastNodes);
@@ -625,6 +668,11 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
         int rc = ensureFastScene(ctx);
         if (rc != RT_OK) return rc;
         scene = &ctx->fastScene;
+    }
+    if (!statsOnly) {
+        // shadow rays visit the parents that lie towards the sun first (re-sorted when the sun has moved)
+        int rc = refreshAnyOrder(ctx, pc.sunDirection);
+        if (rc != RT_OK) return rc;
     }
     if (ctx->optPipeline == 2 && pathTrace && pc.raysPerPixel >= 1 && ctx->scene.objectCount < 65535)   // object indices are packed in 16 bits
         return launchWavefront(ctx, pc, L, statsOnly, countBuild, first, last);
@@ -906,6 +954,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b) try
     ctx->sceneBytes = rl.dObjects.size() * sizeof(DevObject) + rl.dNodes.size() * sizeof(DevNode) + rl.dTris.size() * sizeof(DevTri) +
                       nrms.size() * sizeof(DevNrm) + b->materials.count * sizeof(DevMaterial);
     ctx->hObjects = std::move(rl.dObjects);
+    ctx->hFastObjects.clear();
+    std::memset(ctx->anyOrderSun, 0xff, sizeof(ctx->anyOrderSun));
     ctx->hNodes = std::move(rl.dNodes);
     ctx->hTris = std::move(rl.dTris);
     ctx->haveScene = true;
