@@ -567,7 +567,8 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
             // Descent. A lane that reaches a leaf leaves this loop and waits for the others, so
             // that the triangle tests below run once for all the leaves the wave has reached
             // rather than once per lane (each lane still performs its own steps in its own order).
-            while ((unsigned)cur < (unsigned)RT_NONE) {
+            int budget = COUNT ? 0x7fffffff : RT_DESCENT_CAP;
+            while ((unsigned)cur < (unsigned)RT_NONE && budget-- > 0) {
                 NodeVisit nv;
                 visit_node(S, cur, lo, linv, __any(parL), tMin, nv);
                 int2 refs = nv.refs;
@@ -600,6 +601,7 @@ __device__ __forceinline__ bool trace(const DevScene& S, int parentCount, V3 org
                 }
             }
             if (cur == RT_NONE) break;
+            if (cur >= 0) continue;      // descent cut short: the leaves the other lanes have reached first
             {
                 int k = ~cur;
                 for (;;) {
@@ -1063,7 +1065,8 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
         int cur = root, sp = 0;
         const bool nearFirst = NF && root >= S.nearFirstBase;   // wave-uniform: a rebuilt tree, nearer child first
         for (;;) {
-            while ((unsigned)cur < (unsigned)RT_NONE) {
+            int budget = RT_DESCENT_CAP;
+            while ((unsigned)cur < (unsigned)RT_NONE && budget-- > 0) {
                 NodeVisit nv;
                 visit_node(S, cur, lo, linv, __any(parL), tMin, nv);
                 int2 refs = nv.refs;
@@ -1090,7 +1093,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
                     }
                 }
             }
-            if (cur != RT_NONE) {
+            if (cur < 0) {      // at a leaf (a lane whose descent was cut short goes on in the next round)
                 int k = ~cur;
                 bool stop = false;
                 for (;;) {
