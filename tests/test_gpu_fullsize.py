@@ -70,7 +70,7 @@ def generated(tmp_path_factory):
 
 
 def test_default_scene_2560x1369_multi_frame_launch(R, default_scene_arrays):
-    """BASELINE configs[1] as the benchmark runs it: ONE rt_render_frames call of 8 frames on the default
+    """The headline benchmark configuration as the benchmark runs it: ONE rt_render_frames call of 8 frames on the default
     pipeline (two samples per lane, 8 frames per launch) at 2560x1369, against 8 single-frame dispatches
     of the lock-step kernel and against oracle windows."""
     W, H = 2560, 1369
@@ -135,7 +135,7 @@ def test_pair_kernel_is_what_runs(R, default_scene_arrays):
 
 @pytest.mark.parametrize("name", ["heightfield", "blob_grid"])
 def test_generated_configs_full_size(R, generated, name):
-    """BASELINE configs[2] (100 352-triangle height field, 1920x1080) and the scene of configs[4]
+    """Benchmark configuration 2 (100 352-triangle height field, 1920x1080) and the scene of configuration 4
     (64 x 15 616 = 999 424 stored triangles, diffuse / metal / glass, 1920x1080): pipelines 0, 2 and the
     default 3 give one image, every counting build gives one set of counters, oracle windows match."""
     desc, scene, arrays, pc, depth, tris = generated[name]
@@ -180,7 +180,7 @@ def test_generated_configs_full_size(R, generated, name):
 
 
 def test_default_scene_3840x2160_one_launch(R, default_scene_arrays):
-    """BASELINE configs[3]'s image size: one launch of 8 frames at 3840x2160, twice (same bits), against
+    """Benchmark configuration 3's image size: one launch of 8 frames at 3840x2160, twice (same bits), against
     the in-order accumulation of single frames, against an oracle window, and as rank 1 of a 2-way
     sample split (frames 1, 3, 5, ...)."""
     W, H = 3840, 2160

@@ -96,7 +96,7 @@ def test_default_scene_bit_exact_vs_golden_and_oracle(R, rdr, default_scene_arra
 
 
 def test_config1_1280x720_full_frame_bit_exact(R, rdr, default_scene_arrays):
-    """BASELINE config 1: default scene, 1280x720, 1 spp, shipped bounce count, frame 0."""
+    """Benchmark configuration 0: default scene, 1280x720, 1 spp, shipped bounce count, frame 0."""
     W, H = 1280, 720
     rdr.set_option(R.RT_OPT_FAST_MATH, 0)
     opc = scenes.make_pc(default_scene_arrays, W, H)
@@ -356,7 +356,7 @@ def test_sample_split_merge_and_resolve(R, rdr, default_scene_arrays):
 
 
 def test_full_size_properties(R, rdr, default_scene_arrays):
-    """BASELINE config 2 size (2560x1369), too big for the oracle in a test: size-independent properties."""
+    """Benchmark configuration 1 size (2560x1369), too big for the oracle in a test: size-independent properties."""
     W, H = 2560, 1369
     rdr.set_option(R.RT_OPT_FAST_MATH, 0)
     opc = scenes.make_pc(default_scene_arrays, W, H, accumulateFrames=0)
