@@ -37,8 +37,8 @@ hipError_t rt_launch_megakernel_strict(const DevScene*, const rt_push_constants*
                                        DevCounters*, int, int, hipStream_t);
 hipError_t rt_launch_megakernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
                                      DevCounters*, int, int, hipStream_t);
-hipError_t rt_launch_pairkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, hipStream_t);
-hipError_t rt_launch_pairkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, hipStream_t);
+hipError_t rt_launch_pairkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, int, hipStream_t);
+hipError_t rt_launch_pairkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, int, hipStream_t);
 hipError_t rt_launch_schedkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
                                         DevCounters*, int, int, unsigned long long*, int, hipStream_t, unsigned long long*);
 hipError_t rt_launch_schedkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
@@ -688,9 +688,11 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
         // one workgroup of 16 waves per compute unit; its path waves pull tiles from a counter
         auto fn = ctx->optFast ? rt_launch_teamkernel_fast : rt_launch_teamkernel_strict;
         e = fn(scene, &pc, &L, ctx->accum, ctx->draw, ctx->dQueue, std::max(1, ctx->computeUnits), ctx->teamWalkers, ctx->wfRefill, ctx->stream);
-    } else if (ctx->optPipeline == 3 && pc.renderMode == 0 && !statsOnly && pc.raysPerPixel >= 1 && (long long)frames * pc.raysPerPixel >= 2) {
+    } else if (ctx->optPipeline == 3 && pc.renderMode == 0 && !statsOnly && pc.raysPerPixel >= 1 &&
+               ((long long)frames * pc.raysPerPixel >= 2 || (L.tileSize & 15) == 0)) {
+        // two samples of a pixel per lane; a launch that holds one sample per pixel pairs two pixels instead
         auto fn = ctx->optFast ? rt_launch_pairkernel_fast : rt_launch_pairkernel_strict;
-        e = fn(scene, &pc, &L, ctx->accum, ctx->draw, ctx->stream);
+        e = fn(scene, &pc, &L, ctx->accum, ctx->draw, (long long)frames * pc.raysPerPixel < 2 ? 1 : 0, ctx->stream);
     } else {
         // the depth / box views and the degenerate raysPerPixel <= 0 case stay on the lock-step kernel
         auto fn = ctx->optFast ? rt_launch_megakernel_fast : rt_launch_megakernel_strict;

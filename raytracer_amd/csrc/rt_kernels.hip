@@ -1330,7 +1330,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_MEGA_WAVE
 #ifndef RT_PAIR_WAVES
 #define RT_PAIR_WAVES 4
 #endif
-template <bool NF>
+// PIX: the lane's two paths are the same sample of two PIXELS (x, y) and (x, y + 1) - the wave covers 8 x 16
+// pixels - instead of two samples of one pixel: the form a launch takes that holds a single sample per
+// pixel (one frame of 1 ray per pixel, the reference's interactive dispatch). Same arithmetic per sample.
+template <bool NF, bool PIX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVES))) void RT_SYM(rt_pairkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
                                                             float4* __restrict__ accum, float4* __restrict__ out)
 {
@@ -1343,7 +1346,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
     RT_SEC_BEGIN(secKernel);
 
     const int wavesX = L.tileSize >> 3;
-    const int wavesPerTile = wavesX * wavesX;
+    const int wavesPerTile = PIX ? wavesX * (wavesX >> 1) : wavesX * wavesX;
     const int ownedTile = blockIdx.x / wavesPerTile;
     const int sub = blockIdx.x - ownedTile * wavesPerTile;
     const int tile = L.tileRank + ownedTile * L.tileWorld;
@@ -1351,31 +1354,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
     rt_tile_of_position(tile, L.tilesX, &tx, &ty);
     const int sy = sub / wavesX, sx = sub - sy * wavesX;
     const int x = tx * L.tileSize + sx * 8 + (lane & 7);
-    const int y = ty * L.tileSize + sy * 8 + (lane >> 3);
+    const int y = PIX ? ty * L.tileSize + sy * 16 + 2 * (lane >> 3) : ty * L.tileSize + sy * 8 + (lane >> 3);
     if (!(x < L.width && y < L.height)) return;
-    const size_t idx = (size_t)y * (size_t)L.width + (size_t)x;
+    // q-th path of the lane: pixel (x, yq[q]); without PIX both are the lane's one pixel
+    const int yq[2] = { y, PIX ? y + 1 : y };
+    const bool have[2] = { true, PIX ? (y + 1 < L.height) : true };
+    const size_t idxq[2] = { (size_t)y * (size_t)L.width + (size_t)x, (size_t)(have[1] ? yq[1] : y) * (size_t)L.width + (size_t)x };
+    const size_t idx = idxq[0];
 
     const int rpp = pc.raysPerPixel;
-    const int total = L.frames * rpp;                 // samples of this pixel in this launch
+    const int total = L.frames * rpp;                 // samples of a pixel in this launch
     const int bounces = pc.maxBounces + 1;
     const float raysPerPixelRatio = 1.0f / (float)rpp;
     const V3 sunDirN = normalize3(-ld3(pc.sunDirection));
-    V3 nc = mk(0.0f, 0.0f, 0.0f);
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    V3 nc = mk(0.0f, 0.0f, 0.0f), ncB = mk(0.0f, 0.0f, 0.0f);
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), accB = acc;
 
-    for (int n = 0; n < total; n += 2) {
+    for (int n = 0; n < total; n += PIX ? 1 : 2) {
         PathState P[2];
+        int mq[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int m = n + q;
+            const int m = PIX ? n : n + q;
+            mq[q] = m;
             PathState& p = P[q];
-            p.alive = m < total;
+            p.alive = PIX ? have[q] : m < total;
             p.shadow = false;
             p.throughput = mk(1.0f, 1.0f, 1.0f);
             p.result = mk(0.0f, 0.0f, 0.0f);
             p.sun = mk(0.0f, 0.0f, 0.0f);
             p.so = mk(0.0f, 0.0f, 0.0f);
-            Ray ray = get_ray(pc, x, y, pair_seed(pc, L, x, y, m, rpp));
+            Ray ray = get_ray(pc, x, yq[q], pair_seed(pc, L, x, yq[q], m, rpp));
             p.o = ray.o; p.d = ray.d;
         }
         for (int bounce = 0; bounce < bounces; ++bounce) {
@@ -1385,8 +1394,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             trace_pair<false, NF>(S, pc.parentBVHCount, P[0].o, dirA, P[0].alive, bA, P[1].o, dirB, P[1].alive, bB, 0.001f, 1e20f, stack);
             // (the seed of a sample is recomputed where it is needed rather than carried through the walks)
             RT_SEC_BEGIN(secShade);
-            pair_shade(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, y, n, rpp));
-            pair_shade(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, y, n + 1, rpp));
+            pair_shade(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, yq[0], mq[0], rpp));
+            pair_shade(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, yq[1], mq[1], rpp));
             RT_SEC_END(4, secShade);
             if (P[0].shadow || P[1].shadow) {
                 trace_pair<true, NF>(S, pc.parentBVHCount, P[0].so, sunDirN, P[0].shadow, bA, P[1].so, sunDirN, P[1].shadow, bB, 0.001f, 1e20f, stack);
@@ -1394,19 +1403,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
                 if (P[1].shadow && bB.object < 0) P[1].result = P[1].result + P[1].sun;
             }
         }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int m = n + q;
-            if (m >= total) break;
-            nc = nc + P[q].result;
-            const int fr = m / rpp, i = m - fr * rpp;
+        if (PIX) {
+            // one sample of each of the two pixels
+            const int fr = n / rpp, i = n - fr * rpp;
+            nc = nc + P[0].result;
+            ncB = ncB + P[1].result;
             if (i == rpp - 1) {
-                // end of a frame: the pixel goes through memory as in the one-sample kernel
-                acc = accum[idx];
+                acc = accum[idxq[0]];
                 nc = nc * raysPerPixelRatio;
                 acc.x += nc.x; acc.y += nc.y; acc.z += nc.z;
-                accum[idx] = acc;
-                if (m + 1 < total) nc = mk(0.0f, 0.0f, 0.0f);
+                accum[idxq[0]] = acc;
+                if (have[1]) {
+                    accB = accum[idxq[1]];
+                    ncB = ncB * raysPerPixelRatio;
+                    accB.x += ncB.x; accB.y += ncB.y; accB.z += ncB.z;
+                    accum[idxq[1]] = accB;
+                }
+                if (n + 1 < total) { nc = mk(0.0f, 0.0f, 0.0f); ncB = nc; }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = n + q;
+                if (m >= total) break;
+                nc = nc + P[q].result;
+                const int fr = m / rpp, i = m - fr * rpp;
+                if (i == rpp - 1) {
+                    // end of a frame: the pixel goes through memory as in the one-sample kernel
+                    acc = accum[idx];
+                    nc = nc * raysPerPixelRatio;
+                    acc.x += nc.x; acc.y += nc.y; acc.z += nc.z;
+                    accum[idx] = acc;
+                    if (m + 1 < total) nc = mk(0.0f, 0.0f, 0.0f);
+                }
             }
         }
     }
@@ -1415,6 +1444,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
     float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(nc.x, nc.y, nc.z, 1.0f);
     avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
     out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
+    if (PIX && have[1]) {
+        float4 avgB = pc.accumulateFrames == 1 ? accB : make_float4(ncB.x, ncB.y, ncB.z, 1.0f);
+        avgB.x *= accumulationMultiplier; avgB.y *= accumulationMultiplier; avgB.z *= accumulationMultiplier;
+        out[idxq[1]] = make_float4(linear_to_gamma(avgB.x), linear_to_gamma(avgB.y), linear_to_gamma(avgB.z), avgB.w);
+    }
 #ifdef RT_SECTION_TIMERS
     if (lane == __ffsll((long long)__ballot(true)) - 1) {
         unsigned* a = rt_sec_lds();
@@ -2542,18 +2576,21 @@ extern "C" hipError_t RT_SYM(rt_launch_megakernel)(const DevScene* S, const rt_p
 }
 
 extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_push_constants* pc, const DevLaunch* L,
-                                                   void* accum, void* out, hipStream_t stream)
+                                                   void* accum, void* out, int pixelPairs, hipStream_t stream)
 {
     const int wavesX = L->tileSize / 8;
-    const long long blocks = (long long)L->ownedTiles * wavesX * wavesX;
+    if (pixelPairs && (L->tileSize & 15)) return hipErrorInvalidValue;      // 8 x 16 pixel footprints need whole 16-row bands
+    const long long blocks = (long long)L->ownedTiles * wavesX * (pixelPairs ? wavesX / 2 : wavesX);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
-    // two builds of one kernel: <true> knows rebuilt trees (near-first traversal), <false> has that handling compiled out
-    if (S->nearFirstBase != 0x7fffffff)
-        hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<true>, dim3((unsigned)blocks), dim3(64), lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else
-        hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<false>, dim3((unsigned)blocks), dim3(64), lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    const dim3 grid((unsigned)blocks), block(64);
+    // four builds of one kernel: <NF> knows rebuilt trees (near-first traversal), <PIX> pairs two pixels instead of two samples
+    const bool nf = S->nearFirstBase != 0x7fffffff;
+    if (nf && pixelPairs) hipLaunchKernelGGL((RT_SYM(rt_pairkernel)<true, true>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (nf) hipLaunchKernelGGL((RT_SYM(rt_pairkernel)<true, false>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (pixelPairs) hipLaunchKernelGGL((RT_SYM(rt_pairkernel)<false, true>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else hipLaunchKernelGGL((RT_SYM(rt_pairkernel)<false, false>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
     return hipGetLastError();
 }
 

@@ -116,14 +116,15 @@ def test_default_scene_2560x1369_multi_frame_launch(R, default_scene_arrays):
 
 def test_pair_kernel_is_what_runs(R, default_scene_arrays):
     """rt_render_frames with >= 2 samples of a pixel per launch runs the two-samples-per-lane kernel; a
-    launch with an odd number of samples ends on a half-empty pair. Single frames run the lock-step
-    kernel. Both against the oracle, at a ragged size."""
+    launch with an odd number of samples ends on a half-empty pair; a launch with ONE sample per pixel
+    runs the same kernel with two vertically adjacent pixels per lane (the last row of an odd-height
+    image has no partner). All against the oracle, at a ragged size."""
     W, H = 333, 187
     r = R.Renderer(0)
     try:
         r.upload_scene(default_scene_arrays); r.resize(W, H)
         opc = scenes.make_pc(default_scene_arrays, W, H)
-        for count in (2, 5, 8, 11):
+        for count in (1, 2, 5, 8, 11):
             r.clear_accumulation()
             r.render_frames(to_pc(R, opc), 0, 1, count)
             acc = r.read_image(R.RT_IMAGE_ACCUM); out = r.read_image(R.RT_IMAGE_DRAW)
