@@ -1330,13 +1330,109 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_MEGA_WAVE
 #ifndef RT_PAIR_WAVES
 #define RT_PAIR_WAVES 4
 #endif
-// PIX: the lane's two paths are the same sample of two PIXELS (x, y) and (x, y + 1) - the wave covers 8 x 16
-// pixels - instead of two samples of one pixel: the form a launch takes that holds a single sample per
-// pixel (one frame of 1 ray per pixel, the reference's interactive dispatch). Same arithmetic per sample.
-template <bool NF, bool PIX>
+template <bool NF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVES))) void RT_SYM(rt_pairkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
                                                             float4* __restrict__ accum, float4* __restrict__ out)
 {
+    extern __shared__ uint2 stackMem[];
+    const int lane = threadIdx.x;
+    uint2* stack = stackMem + lane;
+#ifdef RT_SECTION_TIMERS
+    if (lane < 8) rt_sec_lds()[lane] = 0;
+#endif
+    RT_SEC_BEGIN(secKernel);
+
+    const int wavesX = L.tileSize >> 3;
+    const int wavesPerTile = wavesX * wavesX;
+    const int ownedTile = blockIdx.x / wavesPerTile;
+    const int sub = blockIdx.x - ownedTile * wavesPerTile;
+    const int tile = L.tileRank + ownedTile * L.tileWorld;
+    int tx, ty;
+    rt_tile_of_position(tile, L.tilesX, &tx, &ty);
+    const int sy = sub / wavesX, sx = sub - sy * wavesX;
+    const int x = tx * L.tileSize + sx * 8 + (lane & 7);
+    const int y = ty * L.tileSize + sy * 8 + (lane >> 3);
+    if (!(x < L.width && y < L.height)) return;
+    const size_t idx = (size_t)y * (size_t)L.width + (size_t)x;
+
+    const int rpp = pc.raysPerPixel;
+    const int total = L.frames * rpp;                 // samples of this pixel in this launch
+    const int bounces = pc.maxBounces + 1;
+    const float raysPerPixelRatio = 1.0f / (float)rpp;
+    const V3 sunDirN = normalize3(-ld3(pc.sunDirection));
+    V3 nc = mk(0.0f, 0.0f, 0.0f);
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+    for (int n = 0; n < total; n += 2) {
+        PathState P[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = n + q;
+            PathState& p = P[q];
+            p.alive = m < total;
+            p.shadow = false;
+            p.throughput = mk(1.0f, 1.0f, 1.0f);
+            p.result = mk(0.0f, 0.0f, 0.0f);
+            p.sun = mk(0.0f, 0.0f, 0.0f);
+            p.so = mk(0.0f, 0.0f, 0.0f);
+            Ray ray = get_ray(pc, x, y, pair_seed(pc, L, x, y, m, rpp));
+            p.o = ray.o; p.d = ray.d;
+        }
+        for (int bounce = 0; bounce < bounces; ++bounce) {
+            if (!(P[0].alive || P[1].alive)) break;
+            const V3 dirA = normalize3(P[0].d), dirB = normalize3(P[1].d);
+            Best bA, bB;
+            trace_pair<false, NF>(S, pc.parentBVHCount, P[0].o, dirA, P[0].alive, bA, P[1].o, dirB, P[1].alive, bB, 0.001f, 1e20f, stack);
+            // (the seed of a sample is recomputed where it is needed rather than carried through the walks)
+            RT_SEC_BEGIN(secShade);
+            pair_shade(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, y, n, rpp));
+            pair_shade(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, y, n + 1, rpp));
+            RT_SEC_END(4, secShade);
+            if (P[0].shadow || P[1].shadow) {
+                trace_pair<true, NF>(S, pc.parentBVHCount, P[0].so, sunDirN, P[0].shadow, bA, P[1].so, sunDirN, P[1].shadow, bB, 0.001f, 1e20f, stack);
+                if (P[0].shadow && bA.object < 0) P[0].result = P[0].result + P[0].sun;
+                if (P[1].shadow && bB.object < 0) P[1].result = P[1].result + P[1].sun;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = n + q;
+            if (m >= total) break;
+            nc = nc + P[q].result;
+            const int fr = m / rpp, i = m - fr * rpp;
+            if (i == rpp - 1) {
+                // end of a frame: the pixel goes through memory as in the one-sample kernel
+                acc = accum[idx];
+                nc = nc * raysPerPixelRatio;
+                acc.x += nc.x; acc.y += nc.y; acc.z += nc.z;
+                accum[idx] = acc;
+                if (m + 1 < total) nc = mk(0.0f, 0.0f, 0.0f);
+            }
+        }
+    }
+    const int lastFrame = pc.frame + (L.frames - 1) * L.frameStride;
+    const float accumulationMultiplier = pc.accumulateFrames == 1 ? 1.0f / (float)(lastFrame + 1) : 1.0f;
+    float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(nc.x, nc.y, nc.z, 1.0f);
+    avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
+    out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
+#ifdef RT_SECTION_TIMERS
+    if (lane == __ffsll((long long)__ballot(true)) - 1) {
+        unsigned* a = rt_sec_lds();
+        a[0] = (unsigned)__builtin_amdgcn_s_memtime() - secKernel;
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_sectionCycles[k], (unsigned long long)a[k]);
+    }
+#endif
+}
+
+// rt_pairkernel for launches that hold a single sample per pixel (one frame of 1 ray per pixel, the
+// reference's interactive dispatch): the lane's two paths are the same sample of two PIXELS, (x, y) and
+// (x, y + 1) - the wave covers 8 x 16 pixels - instead of two samples of one pixel. Same arithmetic per
+// sample. (A kernel of its own rather than a flag of rt_pairkernel: sharing the body cost that kernel 0.7 %.)
+template <bool NF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVES))) void RT_SYM(rt_pixelpairkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
+                                                            float4* __restrict__ accum, float4* __restrict__ out)
+{
+    constexpr bool PIX = true;
     extern __shared__ uint2 stackMem[];
     const int lane = threadIdx.x;
     uint2* stack = stackMem + lane;
@@ -2585,12 +2681,12 @@ extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_p
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
     const dim3 grid((unsigned)blocks), block(64);
-    // four builds of one kernel: <NF> knows rebuilt trees (near-first traversal), <PIX> pairs two pixels instead of two samples
+    // <true> knows rebuilt trees (near-first traversal), <false> has that handling compiled out
     const bool nf = S->nearFirstBase != 0x7fffffff;
-    if (nf && pixelPairs) hipLaunchKernelGGL((RT_SYM(rt_pairkernel)<true, true>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else if (nf) hipLaunchKernelGGL((RT_SYM(rt_pairkernel)<true, false>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else if (pixelPairs) hipLaunchKernelGGL((RT_SYM(rt_pairkernel)<false, true>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else hipLaunchKernelGGL((RT_SYM(rt_pairkernel)<false, false>), grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    if (nf && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<true>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (nf) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<true>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<false>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<false>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
     return hipGetLastError();
 }
 

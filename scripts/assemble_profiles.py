@@ -23,7 +23,7 @@ json.dump({"entries": entries}, open(os.path.join(P, "hbm_traffic.json"), "w"), 
 def rows(name):
     out = {}
     for line in open(os.path.join(G, name)).read().splitlines():
-        m = re.match(r"(\S+)\s+(\S+)\s+sum (\S+)\s+per-dispatch (\S+) \(n=(\d+)\)", line)
+        m = re.match(r"(.*?)\s+(\S+)\s+sum (\S+)\s+per-dispatch (\S+) \(n=(\d+)\)", line)      # kernel names may hold spaces
         if m:
             out[m.group(2)] = float(m.group(4))
     return out
