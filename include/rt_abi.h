@@ -63,9 +63,10 @@ enum {
      * its second ray while other lanes of the wave are still on their first, so the wave waits for
      * the largest sum of two walks instead of twice for the largest walk. Each ray sees objects,
      * nodes and triangles in the reference's order and the samples are added in sequence order:
-     * same results. Other launches (one sample, debug views, counters) use kernel 0. The default:
-     * fastest on scenes whose walks have a long tail (the default scene: +6.5 %), a few per cent
-     * slower than 0 on evenly built BVHs (a regular height field). 4 = path waves + walker waves: a
+     * same results. A launch that holds one sample per pixel (rt_render_frame with 1 ray per pixel)
+     * pairs two vertically adjacent pixels per lane instead (tile sizes that are multiples of 16);
+     * debug views and counters use kernel 0. Runs of consecutive BVH parents are gone through lane by
+     * lane in kernels 0 and 3 (every lane visits the parents its own rays can enter). The default. 4 = path waves + walker waves: a
      * workgroup of 16 waves per compute unit; its path waves (12) run kernel 0's code except the walks of
      * BVH parents, which they hand - one job per ray, through a ring in LDS - to the workgroup's walker
      * waves (4), whose lanes take the next job as soon as they are free. Same arithmetic, same results. */
