@@ -163,6 +163,26 @@ def test_settings_surface_bit_exact(R, rdr, default_scene_arrays, fields):
     assert np.array_equal(bits(acc), bits(o["accum"])) and np.array_equal(bits(out), bits(o["out"]))
 
 
+def test_sun_moving_between_dispatches(R, rdr, default_scene_arrays):
+    """The order in which shadow rays visit the objects is re-sorted when the sun direction changes (towards
+    the sun first); it must change no result: a sun that moves from dispatch to dispatch on ONE context -
+    from above, from the side, from below, switched off, a zero vector, back again - against the oracle.
+    (A zero direction normalises to NaN in the shader as well: the same pixels turn NaN on both sides, and
+    only there the bits - sign and payload of a NaN - are not compared.)"""
+    W, H = 96, 54
+    rdr.set_option(R.RT_OPT_FAST_MATH, 0)
+    for sun, intensity in (((-0.5, -1.0, -0.3), 1.5), ((1.0, -0.1, 0.2), 1.5), ((0.2, 1.0, 0.1), 1.5), ((1.0, -0.1, 0.2), 0.0),
+                           ((0.0, 0.0, 0.0), 1.5), ((-0.5, -1.0, -0.3), 1.5), ((0.0, -1.0, 0.0), 3.0)):
+        opc = scenes.make_pc(default_scene_arrays, W, H, sunDirection=sun, sunIntensity=intensity)
+        acc, out = gpu_frames(R, rdr, opc, [0, 1], W, H)
+        o = oracle_frames(default_scene_arrays, opc, [0, 1], W, H)
+        for got, want in ((acc, o["accum"]), (out, o["out"])):
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(got), nan), sun
+            assert np.array_equal(bits(got)[~nan], bits(want)[~nan]), sun
+            assert not nan.any() or sun == (0.0, 0.0, 0.0)
+
+
 @pytest.mark.parametrize("W,H", [(37, 23), (8, 8), (1, 1), (65, 9), (200, 3)])
 def test_ragged_sizes_bit_exact(R, rdr, default_scene_arrays, W, H):
     rdr.set_option(R.RT_OPT_FAST_MATH, 0)
