@@ -391,6 +391,21 @@ def main():
             out["other_flavour"] = {"flavour": "%s traversal, %s arithmetic" % (names[1 - args.traversal], "FMA-contracted" if args.fast else "strict binary32"),
                                     "value": total_rays * args.steps / odt / 1e6, "unit": "Mrays/s", "ms_per_step": odt / args.steps * 1e3,
                                     "ms_per_frame": odt / args.steps * 1e3 / frames_rank, "launch_ms": okms / launches}
+        if world == 1:
+            # the reference's interactive use: ONE dispatch per frame (rt_render_frame, 1 ray per pixel), after the
+            # timed region; 16 dispatches of frames 0..15 into a cleared accumulation image
+            target.clear()
+            pF = pc.copy()
+            for f in range(2):
+                pF.frame = f
+                r.render_frame(pF)
+            r.sync()
+            t0 = time.perf_counter()
+            for f in range(2, 18):
+                pF.frame = f
+                r.render_frame(pF)
+            r.sync()
+            out["ms_per_single_frame_dispatch"] = (time.perf_counter() - t0) / 16 * 1e3
         if world == 1 and args.single_dispatch:
             # the other reading of "64 spp": ONE dispatch with raysPerPixel = frames (samples seeded by the
             # sample index instead of the frame index, raytrace.comp:779-783), after the timed region
