@@ -239,8 +239,9 @@ int rt_frame_stats_noalloc(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_st
 int rt_schedule_stats(rt_ctx* ctx, const rt_push_constants* pc, uint64_t out[16]);
 
 /* Self-test hook (no counterpart in the reference): applies the kernels' exp2 (which = 0), exp (1),
- * log2 (2) or acos (3) - the functions of rt_math.h that stand in for the GLSL built-ins - to n
- * host floats on the device. A host that includes rt_math.h must get the same bits. Synchronises. */
+ * log2 (2), acos (3) - the functions of rt_math.h that stand in for the GLSL built-ins - or the
+ * random generator's k / 10000 (4, for k = 0 ... 9999) to n host floats on the device. A host that
+ * includes rt_math.h must get the same bits. Synchronises. */
 int rt_math_apply(rt_ctx* ctx, int which, const float* x, float* y, size_t n);
 
 /* Milliseconds the last rt_render_frame(s) call spent on the device, measured with HIP events on

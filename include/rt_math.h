@@ -9,7 +9,8 @@
  * fixed order, so every compiler that does not contract multiply-add pairs (build with
  * -ffp-contract=off) and every machine gives the same bits. Accuracy: exp2 and exp within 2 ulp,
  * log2 within 3 ulp (relative to the result, away from x = 1), acos within 4 ulp on [-1, 1]
- * (tests/test_rt_math.py). Coefficients: scripts/gen_math_coeffs.py.
+ * (tests/test_rt_math.py). Coefficients: scripts/gen_math_coeffs.py. rt_div10000f is the one
+ * function here that asks for a fused multiply-add by name (fmaf); contraction stays off.
  *
  * Usable from C, C++ and HIP device code.
  */
@@ -122,6 +123,17 @@ RT_MATH_FN float rt_acosf(float x)
     const float s = sqrtf(z);
     const float t = s + s * (z * rt_asin_tail(z));
     return x > 0.0f ? t + t : 3.14159274f - (t + t);
+}
+
+/* k / 10000 for k = 0 ... 9999, correctly rounded like the division the shader writes
+ * (`float(seed % 10000) / 10000.0`, Random.glsl:11), without the general division sequence: the product
+ * with the rounded reciprocal plus one fused correction step. Exact for all 10 000 dividends
+ * (tests/test_rt_math.py goes through every one of them); not meant for other arguments. */
+RT_MATH_FN float rt_div10000f(float k)
+{
+    const float c = 1.0f / 10000.0f;
+    const float q0 = k * c;
+    return fmaf(fmaf(-q0, 10000.0f, k), c, q0);
 }
 
 #endif /* RT_MATH_H */

@@ -326,11 +326,12 @@ void orc_sample_square(uint32_t seed, float out2[2])
     out2[0] = o.x; out2[1] = o.y;
 }
 
-/* rt_math.h functions over an array (which: 0 exp2, 1 exp, 2 log2, 3 acos), for the accuracy tests */
+/* rt_math.h functions over an array (which: 0 exp2, 1 exp, 2 log2, 3 acos, 4 div10000), for the accuracy tests */
 void orc_math_apply(int which, const float* x, float* y, size_t n)
 {
     for (size_t i = 0; i < n; ++i)
-        y[i] = which == 0 ? rt_exp2f(x[i]) : which == 1 ? rt_expf(x[i]) : which == 2 ? rt_log2f(x[i]) : rt_acosf(x[i]);
+        y[i] = which == 0 ? rt_exp2f(x[i]) : which == 1 ? rt_expf(x[i]) : which == 2 ? rt_log2f(x[i]) : which == 3 ? rt_acosf(x[i])
+                                                                                                    : rt_div10000f(x[i]);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -463,10 +463,10 @@ class Renderer:
         return sec.value
 
     def math_apply(self, which, x):
-        """The device's rt_math.h functions over an array: which = 'exp2' | 'exp' | 'log2' | 'acos'."""
+        """The device's rt_math.h functions over an array: which = 'exp2' | 'exp' | 'log2' | 'acos' | 'div10000'."""
         x = np.ascontiguousarray(x, np.float32)
         y = np.empty_like(x)
-        self._check(self.lib.rt_math_apply(self.h, {"exp2": 0, "exp": 1, "log2": 2, "acos": 3}[which], x.ctypes.data, y.ctypes.data, x.size))
+        self._check(self.lib.rt_math_apply(self.h, {"exp2": 0, "exp": 1, "log2": 2, "acos": 3, "div10000": 4}[which], x.ctypes.data, y.ctypes.data, x.size))
         return y
 
     def last_render_ms(self):

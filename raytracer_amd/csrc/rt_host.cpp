@@ -1207,7 +1207,7 @@ int rt_produce_render(rt_ctx* ctx, rt_push_constants* pc, int render_frames, con
 
 int rt_math_apply(rt_ctx* ctx, int which, const float* x, float* y, size_t n) try
 {
-    if (!ctx || (n && (!x || !y)) || which < 0 || which > 3) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_math_apply: bad argument");
+    if (!ctx || (n && (!x || !y)) || which < 0 || which > 4) return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_math_apply: bad argument");
     if (n == 0) return RT_OK;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     float *dx = nullptr, *dy = nullptr;

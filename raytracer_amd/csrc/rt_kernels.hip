@@ -91,7 +91,7 @@ __device__ __forceinline__ float rng_hash(uint32_t& seed)
     s *= 0x27d4eb2du;
     s = s ^ (s >> 15);
     seed = s;
-    return (float)(s % 10000u) / 10000.0f;
+    return rt_div10000f((float)(s % 10000u));     // (float)(s % 10000u) / 10000.0f, bit for bit
 }
 // Random.glsl:28-32
 __device__ __forceinline__ float rng_range(float lo, float hi, uint32_t& seed)
@@ -744,9 +744,28 @@ __device__ __forceinline__ DevMaterial load_material(const DevScene& S, int idx)
     return m;
 }
 
-// MaterialScatter + DielectricScatter, raytrace.comp:371-423. `seed` by value.
+// The shader hands `seed` to MaterialScatter by value (raytrace.comp:759), so every bounce of a sample starts
+// the generator from the same state: the unit vector of the Lambert branch (RandomUnitVector, Random.glsl:68)
+// and the one inside the metal branch's RandomOnHemisphere (one `seed += 1` later, Random.glsl:80-82) are
+// functions of the sample's seed alone. The kernels that keep a path per lane across its bounces draw both
+// once per sample - two rejection loops per sample instead of up to two per bounce at wave level.
+struct ScatterDraws { V3 lambert, metal; };
+
+__device__ __forceinline__ ScatterDraws scatter_draws(uint32_t seed)
+{
+    (void)rng_range(0.0f, 1.0f, seed);      // scatterOrReflect: MaterialScatter's first draw
+    ScatterDraws d;
+    uint32_t s = seed;
+    d.lambert = random_unit_vector(s);
+    s = seed + 1u;                          // RandomOnHemisphere's own increment
+    d.metal = random_unit_vector(s);
+    return d;
+}
+
+// MaterialScatter + DielectricScatter, raytrace.comp:371-423. `seed` by value. pre: the sample's two unit
+// vectors drawn ahead (scatter_draws), or null to draw them here.
 __device__ __forceinline__ void material_scatter(const DevMaterial& m, V3 rayDir, const HitRec& rec, uint32_t seed,
-                                                 V3& attenuation, Ray& scattered)
+                                                 V3& attenuation, Ray& scattered, const ScatterDraws* pre = nullptr)
 {
     float scatterOrReflect = rng_range(0.0f, 1.0f, seed);
     if (m.refractionIndex > 0.0f) {
@@ -771,12 +790,15 @@ __device__ __forceinline__ void material_scatter(const DevMaterial& m, V3 rayDir
     const float EPSILON = 1e-4f;
     if (scatterOrReflect < m.smoothness) {
         V3 reflected = reflect3(normalize3(rayDir), rec.normal);
-        reflected = reflected + random_on_hemisphere(rec.normal, seed) * m.fuzziness;
+        V3 fuzz;
+        if (pre) fuzz = dot3(pre->metal, rec.normal) > 0.0f ? pre->metal : -pre->metal;     // Random.glsl:83-87
+        else fuzz = random_on_hemisphere(rec.normal, seed);
+        reflected = reflected + fuzz * m.fuzziness;
         scattered.o = rec.point + reflected * EPSILON;
         scattered.d = normalize3(reflected);
         attenuation = ld3(m.colour);
     } else {
-        V3 sd = rec.normal + random_unit_vector(seed);
+        V3 sd = rec.normal + (pre ? pre->lambert : random_unit_vector(seed));
         const float s = 1e-8f;
         if (fabsf(sd.x) < s && fabsf(sd.y) < s && fabsf(sd.z) < s) sd = rec.normal;
         scattered.o = rec.point + sd * EPSILON;
@@ -794,6 +816,7 @@ __device__ __forceinline__ V3 ray_colour(const DevScene& S, const rt_push_consta
     V3 result = mk(0.0f, 0.0f, 0.0f);
     V3 throughput = mk(1.0f, 1.0f, 1.0f);
     const int bounces = pc.maxBounces + 1;
+    const ScatterDraws draws = scatter_draws(seed);
     for (int bounce = 0; bounce < bounces; ++bounce) {
         V3 dirN = normalize3(ray.d);
         Best best;
@@ -834,7 +857,7 @@ __device__ __forceinline__ V3 ray_colour(const DevScene& S, const rt_push_consta
         V3 attenuation;
         Ray scattered;
         RT_SEC_BEGIN(secScatter);
-        material_scatter(m, ray.d, rec, seed, attenuation, scattered);
+        material_scatter(m, ray.d, rec, seed, attenuation, scattered, &draws);
         RT_SEC_END(5, secScatter);
         throughput = throughput * attenuation;
         ray = scattered;
@@ -859,6 +882,7 @@ struct PathState {
     V3 throughput, result;
     V3 sun;               // sun term of the last hit, added when its shadow ray comes back unblocked
     V3 so;                // origin of that shadow ray
+    ScatterDraws draws;   // the sample's two unit vectors (the same at every bounce)
     bool alive;           // wants a regular GetHit
     bool shadow;          // wants a shadow GetHit
 };
@@ -1162,7 +1186,7 @@ __device__ __forceinline__ void pair_shade(const DevScene& S, const rt_push_cons
     }
     V3 attenuation;
     Ray scattered;
-    material_scatter(m, p.d, rec, seed, attenuation, scattered);
+    material_scatter(m, p.d, rec, seed, attenuation, scattered, &p.draws);
     p.throughput = p.throughput * attenuation;
     p.o = scattered.o;
     p.d = scattered.d;
@@ -1375,8 +1399,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             p.result = mk(0.0f, 0.0f, 0.0f);
             p.sun = mk(0.0f, 0.0f, 0.0f);
             p.so = mk(0.0f, 0.0f, 0.0f);
-            Ray ray = get_ray(pc, x, y, pair_seed(pc, L, x, y, m, rpp));
+            const uint32_t seed = pair_seed(pc, L, x, y, m, rpp);
+            Ray ray = get_ray(pc, x, y, seed);
             p.o = ray.o; p.d = ray.d;
+            p.draws = scatter_draws(seed);
         }
         for (int bounce = 0; bounce < bounces; ++bounce) {
             if (!(P[0].alive || P[1].alive)) break;
@@ -1480,8 +1506,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             p.result = mk(0.0f, 0.0f, 0.0f);
             p.sun = mk(0.0f, 0.0f, 0.0f);
             p.so = mk(0.0f, 0.0f, 0.0f);
-            Ray ray = get_ray(pc, x, yq[q], pair_seed(pc, L, x, yq[q], m, rpp));
+            const uint32_t seed = pair_seed(pc, L, x, yq[q], m, rpp);
+            Ray ray = get_ray(pc, x, yq[q], seed);
             p.o = ray.o; p.d = ray.d;
+            p.draws = scatter_draws(seed);
         }
         for (int bounce = 0; bounce < bounces; ++bounce) {
             if (!(P[0].alive || P[1].alive)) break;
@@ -2628,14 +2656,14 @@ __global__ __launch_bounds__(256) void RT_SYM(rt_resolve_kernel)(const float4* _
     }
 }
 
-// rt_math.h over an array (which: 0 exp2, 1 exp, 2 log2, 3 acos): lets a test compare the device's
+// rt_math.h over an array (which: 0 exp2, 1 exp, 2 log2, 3 acos, 4 div10000): lets a test compare the device's
 // results with the host's bit for bit.
 __global__ __launch_bounds__(256) void RT_SYM(rt_math_kernel)(int which, const float* __restrict__ x, float* __restrict__ y, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride)
-        y[i] = which == 0 ? rt_exp2f(x[i]) : which == 1 ? rt_expf(x[i]) : which == 2 ? rt_log2f(x[i]) : rt_acosf(x[i]);
+        y[i] = which == 0 ? rt_exp2f(x[i]) : which == 1 ? rt_expf(x[i]) : which == 2 ? rt_log2f(x[i]) : which == 3 ? rt_acosf(x[i]) : rt_div10000f(x[i]);
 }
 
 // ---- launchers (called from rt_host.cpp) ---------------------------------------

@@ -61,10 +61,10 @@ def rng_draw(state):
 
 
 def math_apply(which, x):
-    """include/rt_math.h over an array: which = 'exp2' | 'exp' | 'log2' | 'acos'."""
+    """include/rt_math.h over an array: which = 'exp2' | 'exp' | 'log2' | 'acos' | 'div10000'."""
     x = np.ascontiguousarray(x, np.float32)
     y = np.empty_like(x)
-    lib().orc_math_apply({'exp2': 0, 'exp': 1, 'log2': 2, 'acos': 3}[which], x.ctypes.data, y.ctypes.data, x.size)
+    lib().orc_math_apply({'exp2': 0, 'exp': 1, 'log2': 2, 'acos': 3, 'div10000': 4}[which], x.ctypes.data, y.ctypes.data, x.size)
     return y
 
 

@@ -580,6 +580,34 @@ def test_device_math_equals_host_math(R):
         for name, x in cases.items():
             x = x.astype(np.float32)
             assert np.array_equal(bits(r.math_apply(name, x)), bits(O.math_apply(name, x))), name
+        # the generator's k / 10000: all 10 000 dividends, against the division itself
+        k = np.arange(10000, dtype=np.float32)
+        assert np.array_equal(bits(r.math_apply("div10000", k)), bits(k / np.float32(10000.0)))
+    finally:
+        r.close()
+
+
+def test_device_math_accuracy_against_double(R):
+    """The accuracy bars of tests/test_rt_math.py applied to what the DEVICE computes (exp2, exp within 2 ulp,
+    log2 and acos within 4 ulp of double precision), so that a GPU-only run bounds the functions that stand in
+    for the GLSL built-ins and not only their agreement with the host's copy of the same header."""
+    def ulps(y, ref):
+        return np.abs(y.astype(np.float64) - ref) / np.spacing(np.abs(ref.astype(np.float32))).astype(np.float64)
+    rng = np.random.default_rng(7)
+    r = R.Renderer(0)
+    try:
+        x = rng.uniform(-125, 127, 400000).astype(np.float32)
+        assert ulps(r.math_apply("exp2", x), np.exp2(x.astype(np.float64))).max() < 2.0
+        x = rng.uniform(-86, 88, 400000).astype(np.float32)
+        assert ulps(r.math_apply("exp", x), np.exp(x.astype(np.float64))).max() < 2.0
+        x = np.exp(rng.uniform(-80, 80, 400000)).astype(np.float32)
+        ref = np.log2(x.astype(np.float64))
+        far = np.abs(ref) > 0.01
+        assert ulps(r.math_apply("log2", x)[far], ref[far]).max() < 4.0
+        x = rng.uniform(0.5, 2.0, 400000).astype(np.float32)
+        assert np.abs(r.math_apply("log2", x) - np.log2(x.astype(np.float64))).max() < 2e-7
+        x = rng.uniform(-1, 1, 400000).astype(np.float32)
+        assert ulps(r.math_apply("acos", x), np.arccos(x.astype(np.float64))).max() < 4.0
     finally:
         r.close()
 

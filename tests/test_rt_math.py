@@ -30,6 +30,13 @@ def test_accuracy_against_double():
     assert ulps(O.math_apply("acos", x)[ref > 0], ref[ref > 0]).max() < 4.0
 
 
+def test_division_by_10000_is_exact():
+    """The generator's `float(seed % 10000) / 10000.0` (Random.glsl:11) is computed as a product and one fused
+    correction step: every one of the 10 000 dividends must give the correctly rounded quotient."""
+    k = np.arange(10000, dtype=np.float32)
+    assert np.array_equal(O.math_apply("div10000", k).view(np.uint32), (k / np.float32(10000.0)).view(np.uint32))
+
+
 def test_special_values():
     inf, nan = np.float32(np.inf), np.float32(np.nan)
     e2 = O.math_apply("exp2", np.array([0, 1, -1, 10, -126, -149, -151, 128, 200, nan], np.float32))
