@@ -118,13 +118,21 @@ enum {
     RT_OPT_TRAVERSAL = 17, RT_OPT_SAH_MAX_LEAF = 18,
     /* Pipeline 4: walker waves per workgroup of 16 waves (default 4; the other waves are path waves). */
     RT_OPT_TEAM_WALKERS = 19,
+    /* Near-first traversal on pipeline 3, scenes in which no object keeps the reference's order: 1 (default)
+     * = the rebuilt trees are folded into four-child 128-byte records (same boxes, same leaves), the four
+     * children visited nearest first - half as many dependent fetches on a root-to-leaf path; 0 = two-child
+     * records. Other pipelines and mixed scenes always walk two-child records. */
+    RT_OPT_WIDE_RECORDS = 20,
     /* Read-only (rt_get_option) facts about the uploaded scene: traversal stack entries a lane can
      * need (longest chain of two-child records), number of two-child records, and number of
      * triangle records in leaf order (a triangle that several leaves share counts once per leaf). */
     RT_INFO_STACK_DEPTH = 100, RT_INFO_RECORDS = 101, RT_INFO_TRIANGLES = 102,
     /* The same for the near-first scene (built on first use): objects that walk a rebuilt tree, two-child
      * records and triangle records in its arrays, traversal stack entries. */
-    RT_INFO_FAST_OBJECTS = 103, RT_INFO_FAST_RECORDS = 104, RT_INFO_FAST_TRIANGLES = 105, RT_INFO_FAST_STACK_DEPTH = 106
+    RT_INFO_FAST_OBJECTS = 103, RT_INFO_FAST_RECORDS = 104, RT_INFO_FAST_TRIANGLES = 105, RT_INFO_FAST_STACK_DEPTH = 106,
+    /* Four-child records of the near-first scene (0 when the scene has none, see RT_OPT_WIDE_RECORDS) and the
+     * traversal stack entries a lane can need while walking them. */
+    RT_INFO_WIDE_RECORDS = 107, RT_INFO_WIDE_STACK_NEED = 108
 };
 
 /* ---- device context ------------------------------------------------------ */

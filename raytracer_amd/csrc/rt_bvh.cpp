@@ -203,3 +203,67 @@ void rt_triangle_bounds(const DevTri* src, size_t count, float boundsLo[3], floa
     for (size_t i = 0; i < count; ++i) bounds.grow(Builder::triBox(src[i]));
     for (int a = 0; a < 3; ++a) { boundsLo[a] = bounds.lo[a]; boundsHi[a] = bounds.hi[a]; }
 }
+
+// Folds the two-child tree below record `root` (an index into `nodes2`) into four-child records appended
+// to `out`: starting from a record's two children, the inner child with the largest box is replaced by its
+// own two children until four slots are used or only leaves are left. Same boxes, same leaves; a
+// root-to-leaf path becomes about half as many records. Returns the index of the new root record; `need`
+// receives the number of traversal-stack entries a lane can need below it (up to three per level).
+namespace {
+struct Slot4 { float lo[3], hi[3]; int32_t ref; };
+
+int32_t collapse4(const std::vector<DevNode>& nodes2, int32_t root, std::vector<DevNode4>& out, int& need)
+{
+    Slot4 s[4];
+    int n = 0;
+    auto take = [&](const DevNode& nd, int c, Slot4& dst) {
+        for (int a = 0; a < 3; ++a) { dst.lo[a] = nd.lo[a][c]; dst.hi[a] = nd.hi[a][c]; }
+        dst.ref = c == 0 ? nd.first : nd.second;
+    };
+    take(nodes2[(size_t)root], 0, s[n++]);
+    take(nodes2[(size_t)root], 1, s[n++]);
+    while (n < 4) {
+        int pick = -1;
+        float bestArea = -1.0f;
+        for (int i = 0; i < n; ++i) {
+            if (s[i].ref < 0) continue;
+            const float dx = s[i].hi[0] - s[i].lo[0], dy = s[i].hi[1] - s[i].lo[1], dz = s[i].hi[2] - s[i].lo[2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (area > bestArea) { bestArea = area; pick = i; }
+        }
+        if (pick < 0) break;
+        const DevNode& nd = nodes2[(size_t)s[pick].ref];
+        take(nd, 1, s[n++]);
+        take(nd, 0, s[pick]);
+    }
+    const int32_t idx = (int32_t)out.size();
+    out.push_back(DevNode4{});
+    DevNode4 rec{};
+    int below = 0;
+    for (int c = 0; c < 4; ++c) {
+        if (c >= n || !(s[c].ref > RT_REF_LIVE_MIN)) {      // unused slot, or a child nothing can enter
+            for (int a = 0; a < 3; ++a) { rec.lo[a][c] = RT_FAR_PLANE; rec.hi[a][c] = RT_FAR_PLANE; }
+            rec.ref[c] = RT_REF_EMPTY;
+            continue;
+        }
+        for (int a = 0; a < 3; ++a) { rec.lo[a][c] = s[c].lo[a]; rec.hi[a][c] = s[c].hi[a]; }
+        if (s[c].ref >= 0) {
+            int sub = 0;
+            rec.ref[c] = collapse4(nodes2, s[c].ref, out, sub);
+            below = std::max(below, sub);
+        } else {
+            rec.ref[c] = s[c].ref;
+        }
+    }
+    out[(size_t)idx] = rec;
+    need = (n - 1) + below;
+    return idx;
+}
+} // namespace
+
+int32_t rt_collapse4(const std::vector<DevNode>& nodes2, int32_t root, std::vector<DevNode4>& out, int& need)
+{
+    need = 0;
+    if (root < 0) return root;
+    return collapse4(nodes2, root, out, need);
+}

@@ -50,6 +50,14 @@ struct rt_ctx {
     int fastObjects = 0;          // objects that walk a rebuilt tree
     size_t fastNodeCount = 0, fastTriCount = 0;
     int optTraversal = 0, sahMaxLeaf = 4;
+    // the wide twin of an order-free near-first scene (four-child records, pipeline 3 only): same object
+    // boxes, triangles and any-hit tables as fastScene, object roots in dWideNodes
+    DevScene wideScene{};
+    void* dWideObjects = nullptr;
+    void* dWideNodes = nullptr;
+    bool haveWide = false;
+    size_t wideNodeCount = 0;
+    int optWide = 1;
     int teamWalkers = 4;          // pipeline 4: walker waves per 16-wave workgroup
 
     // images

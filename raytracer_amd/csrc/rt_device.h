@@ -52,11 +52,29 @@ struct DevNode {
     int32_t pad[2];
 };
 
+/* Four-child record of the scenes whose hits do not depend on the visiting order (DevScene::nodes4):
+ * a two-child tree of rt_bvh.cpp folded so that one visit tests four boxes and a root-to-leaf path
+ * is half as many dependent fetches. Plane by plane, the four children side by side (packed f32
+ * instructions work on two of them at a time). An unused slot holds a box far outside any scene
+ * (all planes at RT_FAR_PLANE), which no ray interval can reach, so the walk needs no marker test. */
+#define RT_FAR_PLANE 1e30f
+struct DevNode4 {
+    float   lo[3][4];           /* lo[axis][child] */
+    float   hi[3][4];
+    int32_t ref[4];             /* >= 0 DevNode4 index, < 0 leaf (~ref = first DevTri) */
+    int32_t pad[4];
+};
+
 struct DevTri {
     float   v0[3];  int32_t remaining;  /* triangles left in this leaf including this one */
     float   e1[3];  int32_t orig;       /* index into the caller's triangle arrays (and DevNrm) */
     float   e2[3];  int32_t pad;
 };
+
+static_assert(sizeof(DevNode4) == 128, "DevNode4: one 128-byte line per record");
+
+#define RT_WIDE_LDS_LEVELS 16     /* traversal-stack entries of the four-child walk kept in LDS */
+#define RT_WIDE_DEEP_LEVELS 48    /* further entries, in the lane's private memory */
 
 struct DevNrm {
     float n0[4], n1[4], n2[4];
@@ -92,6 +110,12 @@ struct DevScene {
      * near-first scene when no object is scaled below 1), so parents may be tested concurrently and their
      * hits merged by distance. 0 in the reference-order scene. */
     int32_t            orderFree;
+    /* Four-child records (null unless this is the wide twin of an order-free near-first scene: then the
+     * object roots index this array and `nodes` is unused). wideLdsLevels = traversal-stack entries a lane
+     * keeps in LDS; deeper ones go to the lane's private memory. */
+    const DevNode4*    nodes4;
+    int32_t            wideLdsLevels;
+    int32_t            wideStackNeed;   /* entries a lane can need in the worst case */
 };
 
 #if defined(__HIPCC__)

@@ -31,6 +31,7 @@ void rt_mat4_inverse(const float in[16], float out[16]);   // rt_scene.cpp
 int32_t rt_build_sah(const DevTri* src, size_t count, int maxLeaf, std::vector<DevNode>& nodes, std::vector<DevTri>& tris,
                      float boundsLo[3], float boundsHi[3], int& depth);   // rt_bvh.cpp
 void rt_triangle_bounds(const DevTri* src, size_t count, float boundsLo[3], float boundsHi[3]);   // rt_bvh.cpp
+int32_t rt_collapse4(const std::vector<DevNode>& nodes2, int32_t root, std::vector<DevNode4>& out, int& need);   // rt_bvh.cpp
 
 extern "C" {
 hipError_t rt_launch_megakernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
@@ -99,11 +100,13 @@ namespace {
 void freeFastScene(rt_ctx* c)
 {
     c->hFastObjects.clear();
-    for (void** p : { &c->dFastObjects, &c->dFastNodes, &c->dFastTris, &c->dFastAnyOrder }) {
+    for (void** p : { &c->dFastObjects, &c->dFastNodes, &c->dFastTris, &c->dFastAnyOrder, &c->dWideObjects, &c->dWideNodes }) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
     c->haveFast = false;
+    c->haveWide = false;
+    c->wideNodeCount = 0;
     c->fastObjects = 0;
     c->fastNodeCount = c->fastTriCount = 0;
 }
@@ -365,6 +368,7 @@ int refreshAnyOrder(rt_ctx* ctx, const float sunDirection[3])
         RT_HIP(ctx, hipMemcpyAsync(dst, tables.data(), tables.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the staging vector dies here
         scene.anyFirst = anyFirst;
+        if (which) ctx->wideScene.anyFirst = anyFirst;     // the wide twin shares the near-first scene's tables
     }
     std::memcpy(ctx->anyOrderSun, sunDirection, sizeof(ctx->anyOrderSun));
     return RT_OK;
@@ -513,6 +517,41 @@ int ensureFastScene(rt_ctx* ctx)
     for (size_t i = 0; i < P; ++i)
         if (objects[i].root > RT_REF_LIVE_MIN && !eligible[i]) f.orderFree = 0;
     ctx->fastScene = f;
+    // the wide twin: every rebuilt tree folded into four-child records (only when no object keeps the
+    // reference's order, so that the kernel that walks them needs no second kind of record)
+    if (f.orderFree && rebuilt > 0) {
+        std::vector<DevNode4> nodes4;
+        std::vector<DevObject> wide = objects;
+        std::map<int32_t, std::pair<int32_t, int>> folded;      // two-child root -> (four-child root, stack need)
+        int need = 1;
+        for (size_t i = 0; i < P; ++i) {
+            if (wide[i].root < 0) continue;
+            auto it = folded.find(wide[i].root);
+            if (it == folded.end()) {
+                int n = 0;
+                const int32_t r4 = rt_collapse4(nodes, wide[i].root, nodes4, n);
+                it = folded.emplace(wide[i].root, std::make_pair(r4, n)).first;
+            }
+            wide[i].root = it->second.first;
+            need = std::max(need, it->second.second);
+        }
+        if (need <= RT_WIDE_LDS_LEVELS + RT_WIDE_DEEP_LEVELS) {
+            if ((rc = uploadArray(ctx, &ctx->dWideObjects, wide.data(), wide.size() * sizeof(DevObject))) != RT_OK) return rc;
+            if ((rc = uploadArray(ctx, &ctx->dWideNodes, nodes4.data(), nodes4.size() * sizeof(DevNode4))) != RT_OK) return rc;
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DevScene w = f;
+            w.objects = static_cast<const DevObject*>(ctx->dWideObjects);
+            w.nodes = nullptr;
+            w.nodes4 = static_cast<const DevNode4*>(ctx->dWideNodes);
+            w.nearFirstBase = 0;
+            w.wideStackNeed = need;
+            w.wideLdsLevels = std::min(need, RT_WIDE_LDS_LEVELS);
+            w.stackDepth = w.wideLdsLevels;
+            ctx->wideScene = w;
+            ctx->wideNodeCount = nodes4.size();
+            ctx->haveWide = true;
+        }
+    }
     ctx->fastObjects = rebuilt;
     ctx->fastNodeCount = nodes.size();
     ctx->fastTriCount = tris.size();
@@ -668,6 +707,7 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
         int rc = ensureFastScene(ctx);
         if (rc != RT_OK) return rc;
         scene = &ctx->fastScene;
+        if (ctx->optWide && ctx->haveWide && ctx->optPipeline == 3 && pc.raysPerPixel >= 1) scene = &ctx->wideScene;
     }
     if (!statsOnly) {
         // shadow rays visit the parents that lie towards the sun first (re-sorted when the sun has moved)
@@ -811,6 +851,7 @@ int rt_set_option(rt_ctx* ctx, int option, int value) try
         if (value != 0 && value != 1) return rt_fail(ctx, RT_ERR_INVALID_ARG, "traversal must be 0 (reference order) or 1 (near-first on rebuilt trees)");
         ctx->optTraversal = value;
         return RT_OK;
+    case RT_OPT_WIDE_RECORDS: ctx->optWide = value ? 1 : 0; return RT_OK;
     case RT_OPT_SAH_MAX_LEAF:
         if (value < 1 || value > 64) return rt_fail(ctx, RT_ERR_INVALID_ARG, "triangles per rebuilt leaf must be in [1,64]");
         if (value != ctx->sahMaxLeaf) {
@@ -855,6 +896,14 @@ int rt_get_option(rt_ctx* ctx, int option, int* value) try
     case RT_OPT_TEAM_WALKERS: *value = ctx->teamWalkers; return RT_OK;
     case RT_OPT_TRAVERSAL: *value = ctx->optTraversal; return RT_OK;
     case RT_OPT_SAH_MAX_LEAF: *value = ctx->sahMaxLeaf; return RT_OK;
+    case RT_OPT_WIDE_RECORDS: *value = ctx->optWide; return RT_OK;
+    case RT_INFO_WIDE_RECORDS: case RT_INFO_WIDE_STACK_NEED: {
+        if (!ctx->haveScene) { *value = 0; return RT_OK; }
+        int rc = ensureFastScene(ctx);
+        if (rc != RT_OK) return rc;
+        *value = !ctx->haveWide ? 0 : option == RT_INFO_WIDE_RECORDS ? (int)std::min<size_t>(ctx->wideNodeCount, 0x7fffffff) : ctx->wideScene.wideStackNeed;
+        return RT_OK;
+    }
     case RT_INFO_FAST_OBJECTS: case RT_INFO_FAST_RECORDS: case RT_INFO_FAST_TRIANGLES: case RT_INFO_FAST_STACK_DEPTH: {
         if (!ctx->haveScene) { *value = 0; return RT_OK; }
         int rc = ensureFastScene(ctx);

@@ -332,6 +332,104 @@ __device__ __forceinline__ void visit_node(const DevScene& S, int cur, V3 o, V3 
     else node_boxes<false>(S.nodes + cur, o, inv, tMin, r);
 }
 
+// One visit of a four-child record (DevNode4): four slab tests, the children that the ray can enter in front of
+// its closest hit sorted by entry distance. E[k] / R[k], k = 0 nearest; a slot that is missed carries E = +inf.
+// Same plane distances and interval logic as lean_box; the closest hit is folded into the exit distance
+// (min(exit, closest) > entry is "exit > entry and closest > entry").
+struct Visit4 { float E0, E1, E2, E3; int R0, R1, R2, R3; };
+
+// v_min_f32 / v_max_f32 and their three-operand forms as the hardware has them: a quiet NaN operand is
+// ignored (the plane distances of an axis the ray runs parallel to are NaN and must leave the interval alone),
+// and no operand here is ever a signalling NaN, so the canonicalising copies the compiler puts in front of
+// fminf / fmaxf are not needed.
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// The rare case of a ray with an axis it runs parallel to (NaN reciprocal): a child is only entered when the
+// origin lies between its two planes of that axis (raytrace.comp:213-221). Returns the children to drop, one
+// bit each. Kept out of line of the common path.
+__device__ __noinline__ unsigned visit4_parallel(const DevNode4* node, V3 o, V3 inv)
+{
+    const float* f = reinterpret_cast<const float*>(node);
+    const float oc[3] = { o.x, o.y, o.z }, ic[3] = { inv.x, inv.y, inv.z };
+    unsigned drop = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (!(ic[a] != ic[a])) continue;
+        for (int c = 0; c < 4; ++c)
+            if (oc[a] < f[4 * a + c] || oc[a] > f[12 + 4 * a + c]) drop |= 1u << c;
+    }
+    return drop;
+}
+
+__device__ __forceinline__ void visit4(const DevNode4* node, V3 o, V3 inv, bool anyParallel, float tMin, float closest, Visit4& r)
+{
+    const float4* np = reinterpret_cast<const float4*>(node);
+    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+    const int4 refs = *reinterpret_cast<const int4*>(np + 6);
+    const f32x2 ox = { o.x, o.x }, oy = { o.y, o.y }, oz = { o.z, o.z };
+    const f32x2 ix = { inv.x, inv.x }, iy = { inv.y, inv.y }, iz = { inv.z, inv.z };
+    const f32x2 ax0 = (f32x2{ lx.x, lx.y } - ox) * ix, ax1 = (f32x2{ hx.x, hx.y } - ox) * ix;
+    const f32x2 bx0 = (f32x2{ lx.z, lx.w } - ox) * ix, bx1 = (f32x2{ hx.z, hx.w } - ox) * ix;
+    const f32x2 ay0 = (f32x2{ ly.x, ly.y } - oy) * iy, ay1 = (f32x2{ hy.x, hy.y } - oy) * iy;
+    const f32x2 by0 = (f32x2{ ly.z, ly.w } - oy) * iy, by1 = (f32x2{ hy.z, hy.w } - oy) * iy;
+    const f32x2 az0 = (f32x2{ lz.x, lz.y } - oz) * iz, az1 = (f32x2{ hz.x, hz.y } - oz) * iz;
+    const f32x2 bz0 = (f32x2{ lz.z, lz.w } - oz) * iz, bz1 = (f32x2{ hz.z, hz.w } - oz) * iz;
+    const float inf = INFINITY;
+#define RT_CHILD4(E, x0, x1, y0, y1, z0, z1)                                                  \
+    {                                                                                         \
+        const float e_ = hw_max3(hw_min(x0, x1), hw_min(y0, y1), hw_max(hw_min(z0, z1), tMin));      \
+        const float x_ = hw_min3(hw_max(x0, x1), hw_max(y0, y1), hw_min(hw_max(z0, z1), closest));   \
+        E = x_ > e_ ? e_ : inf;                                                               \
+    }
+    float e0, e1, e2, e3;
+    RT_CHILD4(e0, ax0.x, ax1.x, ay0.x, ay1.x, az0.x, az1.x)
+    RT_CHILD4(e1, ax0.y, ax1.y, ay0.y, ay1.y, az0.y, az1.y)
+    RT_CHILD4(e2, bx0.x, bx1.x, by0.x, by1.x, bz0.x, bz1.x)
+    RT_CHILD4(e3, bx0.y, bx1.y, by0.y, by1.y, bz0.y, bz1.y)
+#undef RT_CHILD4
+    if (anyParallel) {
+        const unsigned drop = visit4_parallel(node, o, inv);
+        e0 = (drop & 1u) ? inf : e0; e1 = (drop & 2u) ? inf : e1; e2 = (drop & 4u) ? inf : e2; e3 = (drop & 8u) ? inf : e3;
+    }
+    int r0 = refs.x, r1 = refs.y, r2 = refs.z, r3 = refs.w;
+    // sorting network (0,1) (2,3) (0,2) (1,3) (1,2); entry distances are never NaN
+#define RT_CE(ea, ra, eb, rb)                                                       \
+    {                                                                               \
+        const bool sw_ = eb < ea;                                                   \
+        const float lo_ = hw_min(ea, eb), hi_ = hw_max(ea, eb);                     \
+        const int rl_ = sw_ ? rb : ra, rh_ = sw_ ? ra : rb;                         \
+        ea = lo_; eb = hi_; ra = rl_; rb = rh_;                                     \
+    }
+    RT_CE(e0, r0, e1, r1)
+    RT_CE(e2, r2, e3, r3)
+    RT_CE(e0, r0, e2, r2)
+    RT_CE(e1, r1, e3, r3)
+    RT_CE(e1, r1, e2, r2)
+#undef RT_CE
+    r.E0 = e0; r.E1 = e1; r.E2 = e2; r.E3 = e3;
+    r.R0 = r0; r.R1 = r1; r.R2 = r2; r.R3 = r3;
+}
+
+// Traversal stack of the four-child walk: the first RT_WIDE_LDS_LEVELS entries of a lane in LDS ([depth][lane],
+// as the two-child walks keep theirs), deeper ones - rare - in the lane's private memory.
+typedef __attribute__((address_space(3))) uint2 lds_uint2;
+struct WideDeep { uint2 e[RT_WIDE_DEEP_LEVELS]; };
+__device__ __forceinline__ void wide_push(lds_uint2* lds, WideDeep& deep, int& sp, int ref, float E)
+{
+    if (sp < RT_WIDE_LDS_LEVELS) { lds[sp * 64].x = (uint32_t)ref; lds[sp * 64].y = __float_as_uint(E); }
+    else deep.e[sp - RT_WIDE_LDS_LEVELS] = make_uint2((uint32_t)ref, __float_as_uint(E));
+    ++sp;
+}
+__device__ __forceinline__ uint2 wide_top(lds_uint2* lds, WideDeep& deep, int sp)     // entry sp (already decremented)
+{
+    uint2 e;
+    if (sp < RT_WIDE_LDS_LEVELS) { e.x = lds[sp * 64].x; e.y = lds[sp * 64].y; }
+    else e = deep.e[sp - RT_WIDE_LDS_LEVELS];
+    return e;
+}
+
 struct Counters { int rays, nodeTests, triTests; };
 
 // What a GetHit call keeps while it walks: enough to rebuild the RayHit.
@@ -389,6 +487,9 @@ __device__ __forceinline__ bool triangle_hit(float4 t0, float4 t1, float4 t2, V3
 // (2.60 -> 2.49 ms per frame on the default scene, 4.11 -> 3.40 with 64 BVH parents).
 #ifndef RT_DESCENT_CAP
 #define RT_DESCENT_CAP 6
+#endif
+#ifndef RT_DESCENT_CAP4
+#define RT_DESCENT_CAP4 3   /* the same cut for walks of four-child records */
 #endif
 
 // A run of consecutive BVH parents gone through lane by lane (see walk_run_pair below for the idea):
@@ -902,7 +1003,7 @@ __device__ __forceinline__ void best_reset(Best& b, float tMax)
 // box tested against the ray's closest hit of that moment exactly as the wave-uniform loop does.
 // Different lanes are inside different parents at the same time; object records come through
 // per-lane (vector) loads instead of scalar ones. Same tests in the same order per ray: same bits.
-template <bool ANYHIT, bool NF>
+template <bool ANYHIT, int NF>
 __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, int pos0, int count, V3 oA, V3 dA, V3 winvA, bool liveA, Best& bA,
                                               V3 oB, V3 dB, V3 winvB, bool liveB, Best& bB, bool anyPar, float tMin, uint2* stack)
 {
@@ -932,6 +1033,8 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
     bool parL = false, nearFirst = false;
     int cur = RT_NONE, sp = 0, obj = 0;
     const DevObject* ob = S.objects;
+    lds_uint2* const wlds = (lds_uint2*)stack;
+    WideDeep wdeep;
     for (;;) {
         if (active && cur == RT_NONE) {
             // the ray's next parent; after its last one the lane's other ray; after that the lane is done
@@ -961,12 +1064,53 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
                     linv = ld;
                     parL = lean_inverse(ld, linv);
                     cur = ob->root;
-                    nearFirst = NF && cur >= S.nearFirstBase;
+                    nearFirst = NF == 1 && cur >= S.nearFirstBase;
                     sp = 0;
                 }
             }
         }
         if (!__any(active)) break;
+        if (NF == 2) {
+            if (cur != RT_NONE) {
+                int budget = RT_DESCENT_CAP4;
+                while ((unsigned)cur < (unsigned)RT_NONE && budget-- > 0) {
+                    Visit4 v;
+                    visit4(S.nodes4 + cur, lo, linv, __any(parL), tMin, bw.closest, v);
+                    if (v.E3 < INFINITY) wide_push(wlds, wdeep, sp, v.R3, v.E3);
+                    if (v.E2 < INFINITY) wide_push(wlds, wdeep, sp, v.R2, v.E2);
+                    if (v.E1 < INFINITY) wide_push(wlds, wdeep, sp, v.R1, v.E1);
+                    cur = v.R0;
+                    if (!(v.E0 < INFINITY)) {
+                        cur = RT_NONE;
+                        while (sp > 0) {
+                            --sp;
+                            const uint2 e = wide_top(wlds, wdeep, sp);
+                            if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                        }
+                    }
+                }
+                if (cur < 0) {      // at a leaf (a lane whose descent was cut short goes on in the next round)
+                    int k = ~cur;
+                    bool stop = false;
+                    for (;;) {
+                        const float4* tp = reinterpret_cast<const float4*>(S.tris + k);
+                        const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                        const int remaining = __float_as_int(t0.w);
+                        if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, obj, bw) && ANYHIT) { stop = true; break; }
+                        if (remaining <= 1) break;
+                        ++k;
+                    }
+                    cur = RT_NONE;
+                    if (stop) sp = 0;
+                    while (sp > 0) {
+                        --sp;
+                        const uint2 e = wide_top(wlds, wdeep, sp);
+                        if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                    }
+                }
+            }
+            continue;
+        }
         if (cur != RT_NONE) {
             int budget = RT_DESCENT_CAP;
             while ((unsigned)cur < (unsigned)RT_NONE && budget-- > 0) {
@@ -1022,7 +1166,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
 // GetHit for two rays per lane (see above). onA / onB: the lane has such a ray. ANYHIT: shadow rays,
 // leaf parents first, a ray stops at its first accepted hit.
 // NF: the scene holds rebuilt trees (DevScene::nearFirstBase set); false compiles the near-first handling out.
-template <bool ANYHIT, bool NF>
+template <bool ANYHIT, int NF>
 __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V3 oA, V3 dA, bool onA, Best& bA, V3 oB, V3 dB, bool onB,
                                            Best& bB, float tMin, float tMax, uint2* stack)
 {
@@ -1032,7 +1176,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
     V3 winvA, winvB;
     const bool parWA = lean_inverse(dA, winvA) && onA, parWB = lean_inverse(dB, winvB) && onB;
     const bool permute = ANYHIT && parentCount == S.objectCount;
-    const bool tightScene = NF;   // the near-first scene: boxes are only culls
+    const bool tightScene = NF != 0;   // the near-first scene: boxes are only culls
     for (int pos = 0; pos < parentCount; ++pos) {
         const int i = permute ? S.anyOrder[pos] : pos;
         const DevObject* ob = S.objects + i;   // wave-uniform address
@@ -1042,7 +1186,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
             // consecutive BVH parents (up to 64): RT_RUN_MIN or more are walked lane by lane
             int count = 1;
             while (count < 64 && pos + count < parentCount && S.objects[permute ? S.anyOrder[pos + count] : pos + count].root >= 0) ++count;
-            if (count >= RT_RUN_MIN) {
+            if (count >= (NF == 2 ? 1 : RT_RUN_MIN)) {      // (four-child records are only walked by the run walker)
                 RT_SEC_BEGIN(secRun);
                 walk_run_pair<ANYHIT, NF>(S, permute, pos, count, oA, dA, winvA, liveA, bA, oB, dB, winvB, liveB, bB, __any(parWA || parWB), tMin, stack);
                 RT_SEC_END(ANYHIT ? 6 : 3, secRun);
@@ -1087,7 +1231,8 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
         V3 linv = ld;
         bool parL = lean_inverse(ld, linv);
         int cur = root, sp = 0;
-        const bool nearFirst = NF && root >= S.nearFirstBase;   // wave-uniform: a rebuilt tree, nearer child first
+        const bool nearFirst = NF == 1 && root >= S.nearFirstBase;   // wave-uniform: a rebuilt tree, nearer child first
+        if (NF == 2) continue;      // not reached: every BVH parent of a wide scene is in a run
         for (;;) {
             int budget = RT_DESCENT_CAP;
             while ((unsigned)cur < (unsigned)RT_NONE && budget-- > 0) {
@@ -1354,7 +1499,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_MEGA_WAVE
 #ifndef RT_PAIR_WAVES
 #define RT_PAIR_WAVES 4
 #endif
-template <bool NF>
+template <int NF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVES))) void RT_SYM(rt_pairkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
                                                             float4* __restrict__ accum, float4* __restrict__ out)
 {
@@ -1454,7 +1599,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
 // reference's interactive dispatch): the lane's two paths are the same sample of two PIXELS, (x, y) and
 // (x, y + 1) - the wave covers 8 x 16 pixels - instead of two samples of one pixel. Same arithmetic per
 // sample. (A kernel of its own rather than a flag of rt_pairkernel: sharing the body cost that kernel 0.7 %.)
-template <bool NF>
+template <int NF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVES))) void RT_SYM(rt_pixelpairkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
                                                             float4* __restrict__ accum, float4* __restrict__ out)
 {
@@ -2710,11 +2855,14 @@ extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_p
     const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
     const dim3 grid((unsigned)blocks), block(64);
     // <true> knows rebuilt trees (near-first traversal), <false> has that handling compiled out
-    const bool nf = S->nearFirstBase != 0x7fffffff;
-    if (nf && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<true>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else if (nf) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<true>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else if (pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<false>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<false>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    // <2> walks four-child records (the wide twin of an order-free near-first scene)
+    const bool nf = S->nearFirstBase != 0x7fffffff, wide = S->nodes4 != nullptr;
+    if (wide && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<2>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (wide) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<2>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (nf && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<1>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (nf) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<1>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<0>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<0>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
     return hipGetLastError();
 }
 
