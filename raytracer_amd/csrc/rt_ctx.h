@@ -55,6 +55,9 @@ struct rt_ctx {
     DevScene wideScene{};
     void* dWideObjects = nullptr;
     void* dWideNodes = nullptr;
+    void* dWideAnyOrder = nullptr;      // its own order tables: the wide scene stores the objects in another order
+    void* dWideTlas = nullptr;
+    std::vector<DevObject> hWideObjects;
     bool haveWide = false;
     size_t wideNodeCount = 0;
     int optWide = 1;

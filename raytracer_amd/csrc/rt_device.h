@@ -65,6 +65,12 @@ struct DevNode4 {
     int32_t pad[4];
 };
 
+struct DevBox4 {               /* four boxes, plane by plane (the box part of DevNode4) */
+    float   lo[3][4];
+    float   hi[3][4];
+};
+#define RT_RUN_QUARTETS 16
+
 struct DevTri {
     float   v0[3];  int32_t remaining;  /* triangles left in this leaf including this one */
     float   e1[3];  int32_t orig;       /* index into the caller's triangle arrays (and DevNrm) */
@@ -116,6 +122,16 @@ struct DevScene {
     const DevNode4*    nodes4;
     int32_t            wideLdsLevels;
     int32_t            wideStackNeed;   /* entries a lane can need in the worst case */
+    /* Runs of consecutive BVH parents: runLen[p] = number of BVH parents (root >= 0) that follow one another
+     * from position p of the scene order on, at most 64 (0 where position p holds none); runLenAny the same
+     * for positions of anyOrder. */
+    const int32_t*     runLen;
+    const int32_t*     runLenAny;
+    /* Wide scenes only: the objects are stored leaf parents first, BVH parents after them in the order of a
+     * space-filling curve, and every run of 64 BVH parents has its parents' world boxes once more as
+     * RT_RUN_QUARTETS box quartets (quartet i holds the boxes of the run's parents 4i .. 4i+3, unused slots a box
+     * no ray reaches), from which a ray finds the parents it can enter four at a time. */
+    const DevBox4*     tlas;
 };
 
 #if defined(__HIPCC__)

@@ -100,13 +100,14 @@ namespace {
 void freeFastScene(rt_ctx* c)
 {
     c->hFastObjects.clear();
-    for (void** p : { &c->dFastObjects, &c->dFastNodes, &c->dFastTris, &c->dFastAnyOrder, &c->dWideObjects, &c->dWideNodes }) {
+    for (void** p : { &c->dFastObjects, &c->dFastNodes, &c->dFastTris, &c->dFastAnyOrder, &c->dWideObjects, &c->dWideNodes, &c->dWideAnyOrder, &c->dWideTlas }) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
     c->haveFast = false;
     c->haveWide = false;
     c->wideNodeCount = 0;
+    c->hWideObjects.clear();
     c->fastObjects = 0;
     c->fastNodeCount = c->fastTriCount = 0;
 }
@@ -319,11 +320,13 @@ int uploadArray(rt_ctx* ctx, void** dst, const void* src, size_t bytes)
 // come first (towardsSun = -sunDirection; null or a zero vector: scene order) - what blocks a shadow ray lies
 // between its origin and the sun, and a wave is done with its shadow rays as soon as every one of them is
 // blocked. The order changes no result (a shadow ray only reports whether anything is hit).
-// Layout: anyOrder[P], pad, nextAny[P + 1].
-std::vector<int32_t> orderTables(const std::vector<DevObject>& objects, int32_t& anyFirst, int32_t& leafCount, const float* towardsSun = nullptr)
+// Layout: anyOrder[P], pad, nextAny[P + 1], runLen[P], runLenAny[P] (see DevScene). sortBvhGroup = false keeps the
+// BVH parents in their stored order (the wide scene stores them in the order its box hierarchy needs).
+std::vector<int32_t> orderTables(const std::vector<DevObject>& objects, int32_t& anyFirst, int32_t& leafCount, const float* towardsSun = nullptr,
+                                 bool sortBvhGroup = true)
 {
     const int32_t P = (int32_t)objects.size();
-    std::vector<int32_t> anyOrder, tables(2 * (size_t)P + 2, P);
+    std::vector<int32_t> anyOrder, tables(4 * (size_t)P + 2, P);
     for (int pass = 0; pass < 2; ++pass)
         for (int32_t i = 0; i < P; ++i)
             if ((objects[i].root >= 0) == (pass == 1)) anyOrder.push_back(i);
@@ -340,11 +343,21 @@ std::vector<int32_t> orderTables(const std::vector<DevObject>& objects, int32_t&
         }
         auto nearerTheSun = [&](int32_t x, int32_t y) { return score[(size_t)x] > score[(size_t)y]; };
         std::stable_sort(anyOrder.begin(), anyOrder.begin() + leafCount, nearerTheSun);
-        std::stable_sort(anyOrder.begin() + leafCount, anyOrder.end(), nearerTheSun);
+        if (sortBvhGroup) std::stable_sort(anyOrder.begin() + leafCount, anyOrder.end(), nearerTheSun);
     }
     for (int32_t p = 0; p < P; ++p) {
         tables[p] = anyOrder[p];                                         // anyOrder
         tables[P + 1 + anyOrder[p]] = p + 1 < P ? anyOrder[p + 1] : P;   // nextAny
+    }
+    // runs of BVH parents, counted from the back: in scene order and in the any-hit order
+    for (int pass = 0; pass < 2; ++pass) {
+        int32_t* run = tables.data() + 2 * (size_t)P + 2 + (size_t)pass * (size_t)P;
+        int32_t following = 0;
+        for (int32_t p = P - 1; p >= 0; --p) {
+            const int32_t obj = pass ? anyOrder[p] : p;
+            following = objects[(size_t)obj].root >= 0 ? following + 1 : 0;
+            run[p] = std::min(following, 64);
+        }
     }
     anyFirst = P > 0 ? anyOrder[0] : 0;
     return tables;
@@ -358,17 +371,16 @@ int refreshAnyOrder(rt_ctx* ctx, const float sunDirection[3])
     if (!ctx->haveScene) return RT_OK;
     if (std::memcmp(ctx->anyOrderSun, sunDirection, sizeof(ctx->anyOrderSun)) == 0) return RT_OK;
     const float towards[3] = { -sunDirection[0], -sunDirection[1], -sunDirection[2] };
-    for (int which = 0; which < 2; ++which) {
-        const std::vector<DevObject>& objects = which ? ctx->hFastObjects : ctx->hObjects;
-        void* dst = which ? ctx->dFastAnyOrder : ctx->dAnyOrder;
-        DevScene& scene = which ? ctx->fastScene : ctx->scene;
+    for (int which = 0; which < 3; ++which) {
+        const std::vector<DevObject>& objects = which == 2 ? ctx->hWideObjects : which ? ctx->hFastObjects : ctx->hObjects;
+        void* dst = which == 2 ? ctx->dWideAnyOrder : which ? ctx->dFastAnyOrder : ctx->dAnyOrder;
+        DevScene& scene = which == 2 ? ctx->wideScene : which ? ctx->fastScene : ctx->scene;
         if (!dst || objects.empty()) continue;
         int32_t anyFirst = 0, leafCount = 0;
-        const std::vector<int32_t> tables = orderTables(objects, anyFirst, leafCount, towards);
+        const std::vector<int32_t> tables = orderTables(objects, anyFirst, leafCount, towards, which != 2);
         RT_HIP(ctx, hipMemcpyAsync(dst, tables.data(), tables.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the staging vector dies here
         scene.anyFirst = anyFirst;
-        if (which) ctx->wideScene.anyFirst = anyFirst;     // the wide twin shares the near-first scene's tables
     }
     std::memcpy(ctx->anyOrderSun, sunDirection, sizeof(ctx->anyOrderSun));
     return RT_OK;
@@ -509,6 +521,8 @@ int ensureFastScene(rt_ctx* ctx)
     f.tris = static_cast<const DevTri*>(ctx->dFastTris);
     f.anyOrder = static_cast<const int32_t*>(ctx->dFastAnyOrder);
     f.nextAny = static_cast<const int32_t*>(ctx->dFastAnyOrder) + P + 1;
+    f.runLen = static_cast<const int32_t*>(ctx->dFastAnyOrder) + 2 * P + 2;
+    f.runLenAny = static_cast<const int32_t*>(ctx->dFastAnyOrder) + 3 * P + 2;
     f.anyFirst = anyFirst;
     f.anyLeafCount = leafCount;
     f.stackDepth = std::max(1, std::min(RT_MAX_STACK, depth));
@@ -521,11 +535,35 @@ int ensureFastScene(rt_ctx* ctx)
     // reference's order, so that the kernel that walks them needs no second kind of record)
     if (f.orderFree && rebuilt > 0) {
         std::vector<DevNode4> nodes4;
-        std::vector<DevObject> wide = objects;
         std::map<int32_t, std::pair<int32_t, int>> folded;      // two-child root -> (four-child root, stack need)
         int need = 1;
-        for (size_t i = 0; i < P; ++i) {
-            if (wide[i].root < 0) continue;
+        std::vector<int32_t> leafParents, bvhParents;
+        for (size_t i = 0; i < P; ++i) (objects[i].root >= 0 ? bvhParents : leafParents).push_back((int32_t)i);
+        // BVH parents along a space-filling curve (Morton code of the world box centre, 10 bits per axis): 4, 16 and
+        // 64 consecutive parents are neighbours in space, which is what the box hierarchy over a run groups
+        {
+            float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (int32_t i : bvhParents)
+                for (int a = 0; a < 3; ++a) {
+                    const float c = 0.5f * (objects[(size_t)i].bmin[a] + objects[(size_t)i].bmax[a]);
+                    lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c);
+                }
+            auto morton = [&](int32_t i) {
+                uint32_t code = 0;
+                for (int a = 0; a < 3; ++a) {
+                    const float c = 0.5f * (objects[(size_t)i].bmin[a] + objects[(size_t)i].bmax[a]);
+                    const float ext = hi[a] - lo[a];
+                    uint32_t q = ext > 0.0f ? (uint32_t)std::min(1023.0f, std::max(0.0f, (c - lo[a]) / ext * 1023.0f)) : 0u;
+                    for (int bit = 0; bit < 10; ++bit) code |= ((q >> bit) & 1u) << (3 * bit + a);
+                }
+                return code;
+            };
+            std::stable_sort(bvhParents.begin(), bvhParents.end(), [&](int32_t x, int32_t y) { return morton(x) < morton(y); });
+        }
+        std::vector<DevObject> wide;
+        for (int32_t i : leafParents) wide.push_back(objects[(size_t)i]);
+        for (int32_t i : bvhParents) wide.push_back(objects[(size_t)i]);
+        for (size_t i = leafParents.size(); i < P; ++i) {
             auto it = folded.find(wide[i].root);
             if (it == folded.end()) {
                 int n = 0;
@@ -535,20 +573,43 @@ int ensureFastScene(rt_ctx* ctx)
             wide[i].root = it->second.first;
             need = std::max(need, it->second.second);
         }
+        // per run of 64 BVH parents: the parents' world boxes four by four
+        const size_t B = bvhParents.size(), runs = (B + 63) / 64;
+        std::vector<DevBox4> tlas(runs * RT_RUN_QUARTETS);
+        for (size_t q = 0; q < tlas.size(); ++q)
+            for (int c = 0; c < 4; ++c) {
+                const size_t k = q * 4 + (size_t)c;
+                for (int a = 0; a < 3; ++a) {
+                    tlas[q].lo[a][c] = k < B ? wide[leafParents.size() + k].bmin[a] : RT_FAR_PLANE;
+                    tlas[q].hi[a][c] = k < B ? wide[leafParents.size() + k].bmax[a] : RT_FAR_PLANE;
+                }
+            }
         if (need <= RT_WIDE_LDS_LEVELS + RT_WIDE_DEEP_LEVELS) {
+            int32_t wideAnyFirst = 0, wideLeafCount = 0;
+            const std::vector<int32_t> wideTables = orderTables(wide, wideAnyFirst, wideLeafCount, nullptr, false);
             if ((rc = uploadArray(ctx, &ctx->dWideObjects, wide.data(), wide.size() * sizeof(DevObject))) != RT_OK) return rc;
             if ((rc = uploadArray(ctx, &ctx->dWideNodes, nodes4.data(), nodes4.size() * sizeof(DevNode4))) != RT_OK) return rc;
+            if ((rc = uploadArray(ctx, &ctx->dWideAnyOrder, wideTables.data(), wideTables.size() * sizeof(int32_t))) != RT_OK) return rc;
+            if ((rc = uploadArray(ctx, &ctx->dWideTlas, tlas.data(), tlas.size() * sizeof(DevBox4))) != RT_OK) return rc;
             RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             DevScene w = f;
             w.objects = static_cast<const DevObject*>(ctx->dWideObjects);
             w.nodes = nullptr;
             w.nodes4 = static_cast<const DevNode4*>(ctx->dWideNodes);
+            w.anyOrder = static_cast<const int32_t*>(ctx->dWideAnyOrder);
+            w.nextAny = w.anyOrder + P + 1;
+            w.runLen = w.anyOrder + 2 * P + 2;
+            w.runLenAny = w.anyOrder + 3 * P + 2;
+            w.anyFirst = wideAnyFirst;
+            w.anyLeafCount = wideLeafCount;
+            w.tlas = static_cast<const DevBox4*>(ctx->dWideTlas);
             w.nearFirstBase = 0;
             w.wideStackNeed = need;
             w.wideLdsLevels = std::min(need, RT_WIDE_LDS_LEVELS);
             w.stackDepth = w.wideLdsLevels;
             ctx->wideScene = w;
             ctx->wideNodeCount = nodes4.size();
+            ctx->hWideObjects = wide;
             ctx->haveWide = true;
         }
     }
@@ -993,6 +1054,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b) try
     ctx->scene.materials = static_cast<const DevMaterial*>(ctx->dMaterials);
     ctx->scene.anyOrder = static_cast<const int32_t*>(ctx->dAnyOrder);
     ctx->scene.nextAny = static_cast<const int32_t*>(ctx->dAnyOrder) + P + 1;
+    ctx->scene.runLen = static_cast<const int32_t*>(ctx->dAnyOrder) + 2 * (size_t)P + 2;
+    ctx->scene.runLenAny = static_cast<const int32_t*>(ctx->dAnyOrder) + 3 * (size_t)P + 2;
     ctx->scene.anyFirst = anyFirst;
     ctx->scene.anyLeafCount = anyLeafCount;
     ctx->scene.objectCount = (int32_t)rl.dObjects.size();
