@@ -120,8 +120,12 @@ enum {
     RT_OPT_TEAM_WALKERS = 19,
     /* Near-first traversal on pipeline 3, scenes in which no object keeps the reference's order: 1 (default)
      * = the rebuilt trees are folded into four-child 128-byte records (same boxes, same leaves), the four
-     * children visited nearest first - half as many dependent fetches on a root-to-leaf path; 0 = two-child
-     * records. Other pipelines and mixed scenes always walk two-child records. */
+     * children visited nearest first - half as many dependent fetches on a root-to-leaf path - and, in scenes
+     * with 8 or more objects that own a tree, a hierarchy of such records over the objects' world boxes lets
+     * a ray find the objects it crosses nearest first instead of testing every object's box (the reference
+     * loops over all of them, raytrace.comp:458-471; the hit is the same, only the order of the tests is
+     * not); 2 = four-child records without that hierarchy; 0 = two-child records. Other pipelines and
+     * mixed scenes always walk two-child records. */
     RT_OPT_WIDE_RECORDS = 20,
     /* Read-only (rt_get_option) facts about the uploaded scene: traversal stack entries a lane can
      * need (longest chain of two-child records), number of two-child records, and number of

@@ -267,3 +267,89 @@ int32_t rt_collapse4(const std::vector<DevNode>& nodes2, int32_t root, std::vect
     if (root < 0) return root;
     return collapse4(nodes2, root, out, need);
 }
+
+// Hierarchy over the world boxes of the objects that own a tree (boxes: `count` x {lo xyz, hi xyz}), as
+// four-child records appended to `out`. A child reference of these records is either another such record or
+// RT_REF_INSTANCE + k for object k of the list; returns the root reference (an instance reference when there is
+// a single object) and in `need` the traversal-stack entries a lane can need above the objects' own trees.
+// Two-child tree first - surface-area heuristic over the sorted centroids of each axis, or halving by count
+// when `balanced` (shallowest tree, for scenes whose heuristic tree would be too deep for the stack) - then
+// folded like the objects' trees.
+namespace {
+struct TlasBuilder {
+    std::vector<Prim> prims;
+    std::vector<DevNode> nodes;
+    bool balanced;
+
+    int32_t build(size_t begin, size_t end, Box& bounds)
+    {
+        bounds.clear();
+        Box cb; cb.clear();
+        for (size_t i = begin; i < end; ++i) { bounds.grow(prims[i].b); cb.grow(prims[i].c); }
+        const size_t n = end - begin;
+        if (n == 1) return ~(int32_t)prims[begin].src;
+        size_t mid = begin + n / 2;
+        int axis = 0;
+        for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+        if (!balanced) {
+            float bestCost = INFINITY;
+            int bestAxis = -1; size_t bestMid = mid;
+            std::vector<float> rightArea(n);
+            for (int a = 0; a < 3; ++a) {
+                if (!(cb.hi[a] - cb.lo[a] > 0.0f)) continue;
+                std::sort(prims.begin() + begin, prims.begin() + end, [a](const Prim& x, const Prim& y) { return x.c[a] < y.c[a]; });
+                Box acc; acc.clear();
+                for (size_t i = n - 1; i > 0; --i) { acc.grow(prims[begin + i].b); rightArea[i] = acc.area(); }
+                acc.clear();
+                for (size_t i = 1; i < n; ++i) {
+                    acc.grow(prims[begin + i - 1].b);
+                    const float cost = acc.area() * (float)i + rightArea[i] * (float)(n - i);
+                    if (cost < bestCost) { bestCost = cost; bestAxis = a; bestMid = begin + i; }
+                }
+            }
+            if (bestAxis >= 0) { axis = bestAxis; mid = bestMid; }
+        }
+        {
+            // (re)order along the chosen axis; the heuristic's split position counts from the sorted order
+            std::sort(prims.begin() + begin, prims.begin() + end, [axis](const Prim& x, const Prim& y) { return x.c[axis] < y.c[axis]; });
+        }
+        const int32_t idx = (int32_t)nodes.size();
+        nodes.push_back(DevNode{});
+        Box bl, br;
+        const int32_t rl = build(begin, mid, bl);
+        const int32_t rr = build(mid, end, br);
+        DevNode nd{};
+        for (int a = 0; a < 3; ++a) {
+            nd.lo[a][0] = bl.lo[a]; nd.hi[a][0] = bl.hi[a];
+            nd.lo[a][1] = br.lo[a]; nd.hi[a][1] = br.hi[a];
+        }
+        nd.first = rl;
+        nd.second = rr;
+        nodes[(size_t)idx] = nd;
+        return idx;
+    }
+};
+} // namespace
+
+int32_t rt_build_tlas(const float* boxes, size_t count, bool balanced, std::vector<DevNode4>& out, int& need)
+{
+    need = 0;
+    if (count == 0) return RT_REF_EMPTY;
+    if (count == 1) return RT_REF_INSTANCE;
+    TlasBuilder b;
+    b.balanced = balanced;
+    b.prims.resize(count);
+    for (size_t i = 0; i < count; ++i) {
+        Prim& p = b.prims[i];
+        for (int a = 0; a < 3; ++a) { p.b.lo[a] = boxes[6 * i + a]; p.b.hi[a] = boxes[6 * i + 3 + a]; p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]); }
+        p.src = (uint32_t)i;
+    }
+    Box bounds;
+    const int32_t root2 = b.build(0, count, bounds);
+    const size_t base = out.size();
+    const int32_t root = collapse4(b.nodes, root2, out, need);
+    for (size_t k = base; k < out.size(); ++k)
+        for (int c = 0; c < 4; ++c)
+            if (out[k].ref[c] < 0 && out[k].ref[c] > RT_REF_LIVE_MIN) out[k].ref[c] = RT_REF_INSTANCE + ~out[k].ref[c];
+    return root;
+}

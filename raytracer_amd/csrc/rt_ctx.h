@@ -56,11 +56,11 @@ struct rt_ctx {
     void* dWideObjects = nullptr;
     void* dWideNodes = nullptr;
     void* dWideAnyOrder = nullptr;      // its own order tables: the wide scene stores the objects in another order
-    void* dWideTlas = nullptr;
     std::vector<DevObject> hWideObjects;
     bool haveWide = false;
     size_t wideNodeCount = 0;
     int optWide = 1;
+    int optTlas = 1;              // wide scenes: hierarchy over the BVH parents' boxes
     int teamWalkers = 4;          // pipeline 4: walker waves per 16-wave workgroup
 
     // images

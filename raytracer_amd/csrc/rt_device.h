@@ -30,6 +30,7 @@
 #define RT_REF_EMPTY  ((int32_t)0x80000001)      /* leaf with zero triangles: counted, nothing to test */
 #define RT_REF_DEAD   ((int32_t)0x80000002)      /* child whose box has min > max on an axis: counted, no ray can enter it */
 #define RT_REF_LIVE_MIN ((int32_t)0x80000002)    /* references above this value can be entered */
+#define RT_REF_INSTANCE ((int32_t)0x40000000)    /* four-child records over the objects: RT_REF_INSTANCE + k = object k */
 #define RT_MAX_STACK  32                         /* the shader's `int stack[32]` (raytrace.comp:523) */
 
 struct DevObject {
@@ -65,11 +66,10 @@ struct DevNode4 {
     int32_t pad[4];
 };
 
-struct DevBox4 {               /* four boxes, plane by plane (the box part of DevNode4) */
-    float   lo[3][4];
-    float   hi[3][4];
-};
-#define RT_RUN_QUARTETS 16
+/* Scenes with at least this many BVH parents get a hierarchy over the parents' boxes (DevScene::tlasRoot); with
+ * fewer, the parents are found by testing their boxes one after the other (measured: the default scene with 2 and
+ * the height field with 1 are 5-8 % faster that way, the scene with 64 parents 18 % slower). */
+#define RT_TLAS_MIN_PARENTS 8
 
 struct DevTri {
     float   v0[3];  int32_t remaining;  /* triangles left in this leaf including this one */
@@ -127,11 +127,13 @@ struct DevScene {
      * for positions of anyOrder. */
     const int32_t*     runLen;
     const int32_t*     runLenAny;
-    /* Wide scenes only: the objects are stored leaf parents first, BVH parents after them in the order of a
-     * space-filling curve, and every run of 64 BVH parents has its parents' world boxes once more as
-     * RT_RUN_QUARTETS box quartets (quartet i holds the boxes of the run's parents 4i .. 4i+3, unused slots a box
-     * no ray reaches), from which a ray finds the parents it can enter four at a time. */
-    const DevBox4*     tlas;
+    /* Wide scenes only: the objects are stored leaf parents first, BVH parents after them. */
+    /* Wide scenes: a hierarchy of four-child records over the world boxes of the BVH parents, stored behind the
+     * objects' own records in nodes4 (record indices >= tlasBase; their boxes are in world space, their child
+     * references records of the hierarchy or RT_REF_INSTANCE + object index). tlasRoot: its root reference
+     * (an instance reference when the scene has one BVH parent); RT_REF_EMPTY: the scene has none. */
+    int32_t            tlasRoot;
+    int32_t            tlasBase;
 };
 
 #if defined(__HIPCC__)

@@ -31,6 +31,7 @@ void rt_mat4_inverse(const float in[16], float out[16]);   // rt_scene.cpp
 int32_t rt_build_sah(const DevTri* src, size_t count, int maxLeaf, std::vector<DevNode>& nodes, std::vector<DevTri>& tris,
                      float boundsLo[3], float boundsHi[3], int& depth);   // rt_bvh.cpp
 void rt_triangle_bounds(const DevTri* src, size_t count, float boundsLo[3], float boundsHi[3]);   // rt_bvh.cpp
+int32_t rt_build_tlas(const float* boxes, size_t count, bool balanced, std::vector<DevNode4>& out, int& need);   // rt_bvh.cpp
 int32_t rt_collapse4(const std::vector<DevNode>& nodes2, int32_t root, std::vector<DevNode4>& out, int& need);   // rt_bvh.cpp
 
 extern "C" {
@@ -100,7 +101,7 @@ namespace {
 void freeFastScene(rt_ctx* c)
 {
     c->hFastObjects.clear();
-    for (void** p : { &c->dFastObjects, &c->dFastNodes, &c->dFastTris, &c->dFastAnyOrder, &c->dWideObjects, &c->dWideNodes, &c->dWideAnyOrder, &c->dWideTlas }) {
+    for (void** p : { &c->dFastObjects, &c->dFastNodes, &c->dFastTris, &c->dFastAnyOrder, &c->dWideObjects, &c->dWideNodes, &c->dWideAnyOrder }) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -539,8 +540,8 @@ int ensureFastScene(rt_ctx* ctx)
         int need = 1;
         std::vector<int32_t> leafParents, bvhParents;
         for (size_t i = 0; i < P; ++i) (objects[i].root >= 0 ? bvhParents : leafParents).push_back((int32_t)i);
-        // BVH parents along a space-filling curve (Morton code of the world box centre, 10 bits per axis): 4, 16 and
-        // 64 consecutive parents are neighbours in space, which is what the box hierarchy over a run groups
+        // BVH parents along a space-filling curve (Morton code of the world box centre, 10 bits per axis), so that parents
+        // that follow one another are neighbours in space
         {
             float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
             for (int32_t i : bvhParents)
@@ -573,24 +574,37 @@ int ensureFastScene(rt_ctx* ctx)
             wide[i].root = it->second.first;
             need = std::max(need, it->second.second);
         }
-        // per run of 64 BVH parents: the parents' world boxes four by four
-        const size_t B = bvhParents.size(), runs = (B + 63) / 64;
-        std::vector<DevBox4> tlas(runs * RT_RUN_QUARTETS);
-        for (size_t q = 0; q < tlas.size(); ++q)
-            for (int c = 0; c < 4; ++c) {
-                const size_t k = q * 4 + (size_t)c;
+        const size_t B = bvhParents.size();
+        // the hierarchy over the BVH parents' world boxes, behind the objects' own records
+        const int32_t tlasBase = (int32_t)nodes4.size();
+        int32_t tlasRoot = RT_REF_EMPTY;
+        if (B >= RT_TLAS_MIN_PARENTS && B < (size_t)RT_REF_INSTANCE - P && ctx->optTlas) {
+            std::vector<float> boxes(6 * B);
+            for (size_t k = 0; k < B; ++k)
                 for (int a = 0; a < 3; ++a) {
-                    tlas[q].lo[a][c] = k < B ? wide[leafParents.size() + k].bmin[a] : RT_FAR_PLANE;
-                    tlas[q].hi[a][c] = k < B ? wide[leafParents.size() + k].bmax[a] : RT_FAR_PLANE;
+                    boxes[6 * k + a] = wide[leafParents.size() + k].bmin[a];
+                    boxes[6 * k + 3 + a] = wide[leafParents.size() + k].bmax[a];
                 }
+            for (int attempt = B <= 4096 ? 0 : 1; attempt < 2; ++attempt) {
+                nodes4.resize((size_t)tlasBase);
+                int above = 0;
+                tlasRoot = rt_build_tlas(boxes.data(), B, attempt == 1, nodes4, above);
+                if (need + above <= RT_WIDE_LDS_LEVELS + RT_WIDE_DEEP_LEVELS) { need += above; break; }
+                tlasRoot = RT_REF_EMPTY;
+                nodes4.resize((size_t)tlasBase);
             }
-        if (need <= RT_WIDE_LDS_LEVELS + RT_WIDE_DEEP_LEVELS) {
+            // instance references count the BVH parents; the objects are stored behind the leaf parents
+            if (tlasRoot >= RT_REF_INSTANCE) tlasRoot += (int32_t)leafParents.size();
+            for (size_t k = (size_t)tlasBase; k < nodes4.size(); ++k)
+                for (int c = 0; c < 4; ++c)
+                    if (nodes4[k].ref[c] >= RT_REF_INSTANCE) nodes4[k].ref[c] += (int32_t)leafParents.size();
+        }
+        if (nodes4.size() < (size_t)RT_REF_INSTANCE && need <= RT_WIDE_LDS_LEVELS + RT_WIDE_DEEP_LEVELS) {
             int32_t wideAnyFirst = 0, wideLeafCount = 0;
             const std::vector<int32_t> wideTables = orderTables(wide, wideAnyFirst, wideLeafCount, nullptr, false);
             if ((rc = uploadArray(ctx, &ctx->dWideObjects, wide.data(), wide.size() * sizeof(DevObject))) != RT_OK) return rc;
             if ((rc = uploadArray(ctx, &ctx->dWideNodes, nodes4.data(), nodes4.size() * sizeof(DevNode4))) != RT_OK) return rc;
             if ((rc = uploadArray(ctx, &ctx->dWideAnyOrder, wideTables.data(), wideTables.size() * sizeof(int32_t))) != RT_OK) return rc;
-            if ((rc = uploadArray(ctx, &ctx->dWideTlas, tlas.data(), tlas.size() * sizeof(DevBox4))) != RT_OK) return rc;
             RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             DevScene w = f;
             w.objects = static_cast<const DevObject*>(ctx->dWideObjects);
@@ -602,10 +616,11 @@ int ensureFastScene(rt_ctx* ctx)
             w.runLenAny = w.anyOrder + 3 * P + 2;
             w.anyFirst = wideAnyFirst;
             w.anyLeafCount = wideLeafCount;
-            w.tlas = static_cast<const DevBox4*>(ctx->dWideTlas);
+            w.tlasRoot = tlasRoot;
+            w.tlasBase = tlasBase;
             w.nearFirstBase = 0;
             w.wideStackNeed = need;
-            w.wideLdsLevels = std::min(need, RT_WIDE_LDS_LEVELS);
+            w.wideLdsLevels = std::min(need + 1, RT_WIDE_LDS_LEVELS);      // (the branch-free push writes one slot ahead)
             w.stackDepth = w.wideLdsLevels;
             ctx->wideScene = w;
             ctx->wideNodeCount = nodes4.size();
@@ -912,7 +927,18 @@ int rt_set_option(rt_ctx* ctx, int option, int value) try
         if (value != 0 && value != 1) return rt_fail(ctx, RT_ERR_INVALID_ARG, "traversal must be 0 (reference order) or 1 (near-first on rebuilt trees)");
         ctx->optTraversal = value;
         return RT_OK;
-    case RT_OPT_WIDE_RECORDS: ctx->optWide = value ? 1 : 0; return RT_OK;
+    case RT_OPT_WIDE_RECORDS: {
+        if (value < 0 || value > 2) return rt_fail(ctx, RT_ERR_INVALID_ARG, "wide records must be 0, 1 or 2");
+        const int tlas = value == 2 ? 0 : 1;
+        if (tlas != ctx->optTlas) {        // the wide scene is laid out again at its next use
+            RT_HIP(ctx, hipSetDevice(ctx->device));
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            freeFastScene(ctx);
+        }
+        ctx->optTlas = tlas;
+        ctx->optWide = value ? 1 : 0;
+        return RT_OK;
+    }
     case RT_OPT_SAH_MAX_LEAF:
         if (value < 1 || value > 64) return rt_fail(ctx, RT_ERR_INVALID_ARG, "triangles per rebuilt leaf must be in [1,64]");
         if (value != ctx->sahMaxLeaf) {
@@ -957,7 +983,7 @@ int rt_get_option(rt_ctx* ctx, int option, int* value) try
     case RT_OPT_TEAM_WALKERS: *value = ctx->teamWalkers; return RT_OK;
     case RT_OPT_TRAVERSAL: *value = ctx->optTraversal; return RT_OK;
     case RT_OPT_SAH_MAX_LEAF: *value = ctx->sahMaxLeaf; return RT_OK;
-    case RT_OPT_WIDE_RECORDS: *value = ctx->optWide; return RT_OK;
+    case RT_OPT_WIDE_RECORDS: *value = !ctx->optWide ? 0 : ctx->optTlas ? 1 : 2; return RT_OK;
     case RT_INFO_WIDE_RECORDS: case RT_INFO_WIDE_STACK_NEED: {
         if (!ctx->haveScene) { *value = 0; return RT_OK; }
         int rc = ensureFastScene(ctx);
@@ -1062,6 +1088,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b) try
     ctx->scene.stackDepth = std::max(1, std::min(RT_MAX_STACK, rl.maxDepth));
     ctx->scene.nearFirstBase = 0x7fffffff;
     ctx->scene.orderFree = 0;
+    ctx->scene.tlasRoot = RT_REF_EMPTY;
+    ctx->scene.tlasBase = 0x7fffffff;
     ctx->hStackDepth = ctx->scene.stackDepth;
     ctx->nodeCount = rl.dNodes.size();
     ctx->triCount = rl.dTris.size();

@@ -414,58 +414,6 @@ __device__ __forceinline__ void visit4(const DevNode4* node, V3 o, V3 inv, bool 
 
 // Traversal stack of the four-child walk: the first RT_WIDE_LDS_LEVELS entries of a lane in LDS ([depth][lane],
 // as the two-child walks keep theirs), deeper ones - rare - in the lane's private memory.
-// Which of a quartet's four boxes a ray can enter in front of `closest` (one bit each): the slab tests of visit4
-// without distances or references. Rays with an axis they run parallel to do not come here. With a wave-uniform
-// address the quartet arrives through scalar loads and the packed instructions take it from scalar registers.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(4))) const f32x4 const_f32x4;      // constant address space: scalar loads when the address is uniform
-__device__ __forceinline__ unsigned box4_hits(const_f32x4* np, V3 o, V3 inv, float tMin, float closest)
-{
-    const f32x4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
-    const f32x2 ox = { o.x, o.x }, oy = { o.y, o.y }, oz = { o.z, o.z };
-    const f32x2 ix = { inv.x, inv.x }, iy = { inv.y, inv.y }, iz = { inv.z, inv.z };
-    const f32x2 ax0 = (f32x2{ lx.x, lx.y } - ox) * ix, ax1 = (f32x2{ hx.x, hx.y } - ox) * ix;
-    const f32x2 bx0 = (f32x2{ lx.z, lx.w } - ox) * ix, bx1 = (f32x2{ hx.z, hx.w } - ox) * ix;
-    const f32x2 ay0 = (f32x2{ ly.x, ly.y } - oy) * iy, ay1 = (f32x2{ hy.x, hy.y } - oy) * iy;
-    const f32x2 by0 = (f32x2{ ly.z, ly.w } - oy) * iy, by1 = (f32x2{ hy.z, hy.w } - oy) * iy;
-    const f32x2 az0 = (f32x2{ lz.x, lz.y } - oz) * iz, az1 = (f32x2{ hz.x, hz.y } - oz) * iz;
-    const f32x2 bz0 = (f32x2{ lz.z, lz.w } - oz) * iz, bz1 = (f32x2{ hz.z, hz.w } - oz) * iz;
-    unsigned hits = 0;
-#define RT_BOX4(bit, x0, x1, y0, y1, z0, z1)                                                              \
-    {                                                                                                     \
-        const float e_ = hw_max3(hw_min(x0, x1), hw_min(y0, y1), hw_max(hw_min(z0, z1), tMin));            \
-        const float x_ = hw_min3(hw_max(x0, x1), hw_max(y0, y1), hw_min(hw_max(z0, z1), closest));         \
-        hits |= x_ > e_ ? (bit) : 0u;                                                                      \
-    }
-    RT_BOX4(1u, ax0.x, ax1.x, ay0.x, ay1.x, az0.x, az1.x)
-    RT_BOX4(2u, ax0.y, ax1.y, ay0.y, ay1.y, az0.y, az1.y)
-    RT_BOX4(4u, bx0.x, bx1.x, by0.x, by1.x, bz0.x, bz1.x)
-    RT_BOX4(8u, bx0.y, bx1.y, by0.y, by1.y, bz0.y, bz1.y)
-#undef RT_BOX4
-    return hits;
-}
-
-// The parents of a long run (wide scenes) that two rays can enter, four parents per step from the run's box
-// quartets: scalar loads, packed plane distances, no branches. A ray that is not live comes with a closest hit
-// of -inf, which lies in front of every box. Out of line on purpose: the registers of this loop are then none of
-// the caller's business, whose own loops are at the limit of what four waves per SIMD leave a wave.
-struct RunMasks { unsigned long long a, b; };
-__device__ __noinline__ RunMasks run_prepass_quartets(const DevBox4* quartetsOfRun, int quartets, V3 oA, V3 winvA, float cA, V3 oB, V3 winvB, float cB, float tMin)
-{
-    // the arguments of a function arrive per lane; address and count are the same in every lane
-    const unsigned long long addr = (unsigned long long)quartetsOfRun;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr), hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
-    const_f32x4* q = (const_f32x4*)(((unsigned long long)hi << 32) | lo);
-    quartets = __builtin_amdgcn_readfirstlane(quartets);
-    RunMasks m;
-    m.a = 0; m.b = 0;
-    for (int i = 0; i < quartets; ++i, q += 6) {
-        m.a |= (unsigned long long)box4_hits(q, oA, winvA, tMin, cA) << (4 * i);
-        m.b |= (unsigned long long)box4_hits(q, oB, winvB, tMin, cB) << (4 * i);
-    }
-    return m;
-}
-
 typedef __attribute__((address_space(3))) uint2 lds_uint2;
 struct WideDeep { uint2 e[RT_WIDE_DEEP_LEVELS]; };
 __device__ __forceinline__ void wide_push(lds_uint2* lds, WideDeep& deep, int& sp, int ref, float E)
@@ -539,9 +487,6 @@ __device__ __forceinline__ bool triangle_hit(float4 t0, float4 t1, float4 t2, V3
 // (2.60 -> 2.49 ms per frame on the default scene, 4.11 -> 3.40 with 64 BVH parents).
 #ifndef RT_DESCENT_CAP
 #define RT_DESCENT_CAP 6
-#endif
-#ifndef RT_TLAS_MIN
-#define RT_TLAS_MIN 8       /* parents in a run from which on the run's box quartets are used to find a ray's parents */
 #endif
 #ifndef RT_DESCENT_CAP4
 #define RT_DESCENT_CAP4 3   /* the same cut for walks of four-child records */
@@ -1060,18 +1005,12 @@ __device__ __forceinline__ void best_reset(Best& b, float tMax)
 // per-lane (vector) loads instead of scalar ones. Same tests in the same order per ray: same bits.
 template <bool ANYHIT, int NF>
 __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, int pos0, int count, V3 oA, V3 dA, V3 winvA, bool liveA, Best& bA,
-                                              V3 oB, V3 dB, V3 winvB, bool liveB, Best& bB, bool anyPar, float tMin, uint2* stack,
-                                              const DevBox4* tlas = nullptr)
+                                              V3 oB, V3 dB, V3 winvB, bool liveB, Best& bB, bool anyPar, float tMin, uint2* stack)
 {
     // which parents of the run a ray can enter at all (a parent whose box does not reach inside the
     // closest hit now will not later either: closest hits only come closer)
     unsigned long long mA = 0, mB = 0;
     RT_SEC_BEGIN(secPre);
-    if (NF == 2 && RT_TLAS_MIN <= 64 && tlas != nullptr && !anyPar) {
-        // long runs of a wide scene: four parents per step from the run's box quartets
-        const RunMasks m = run_prepass_quartets(tlas, (count + 3) >> 2, oA, winvA, liveA ? bA.closest : -INFINITY, oB, winvB, liveB ? bB.closest : -INFINITY, tMin);
-        mA = m.a; mB = m.b;
-    } else
     for (int k = 0; k < count; ++k) {
         const int j = permute ? S.anyOrder[pos0 + k] : pos0 + k;
         const DevObject* o2 = S.objects + j;     // wave-uniform address
@@ -1238,9 +1177,113 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
     }
 }
 
+// The BVH parents of a wide scene through the hierarchy over their world boxes (DevScene::tlasRoot): ONE walk per
+// ray that starts in the hierarchy's records (world-space ray), turns into an object's own tree at an instance
+// reference (the ray taken into the object's space there) and comes back to the hierarchy when the traversal
+// stack hands it one of its entries again - the same loop, the same stack, every record's children nearest
+// first, so that the objects themselves are entered nearest first and the ones behind the closest hit not at all.
+// A lane walks ray A, then ray B, while other lanes are wherever their own rays have taken them. (Hits do not
+// depend on the visiting order in these scenes: DevScene::orderFree.)
+template <bool ANYHIT>
+__device__ __forceinline__ void walk_tlas_pair(const DevScene& S, V3 oA, V3 dA, V3 winvA, bool liveA, Best& bA,
+                                               V3 oB, V3 dB, V3 winvB, bool liveB, Best& bB, bool anyParW, float tMin, uint2* stack)
+{
+    if (!__any(liveA || liveB)) return;
+    bool active = liveA || liveB;
+    bool second = !liveA;
+    V3 org = second ? oB : oA, dirN = second ? dB : dA, winv = second ? winvB : winvA;
+    Best bw = second ? bB : bA;
+    V3 lo = org, ld = dirN, linv = winv;
+    bool parL = false;
+    int cur = active ? S.tlasRoot : RT_NONE, sp = 0, obj = 0;
+    const DevObject* ob = S.objects;
+    lds_uint2* const wlds = (lds_uint2*)stack;
+    WideDeep wdeep;
+    const int tlasBase = S.tlasBase;
+    for (;;) {
+        if (active && cur == RT_NONE) {
+            // this ray is done: the lane's other ray, or nothing
+            if (!second) {
+                bA = bw;
+                second = true;
+                if (liveB) {
+                    org = oB; dirN = dB; winv = winvB;
+                    bw = bB;
+                    cur = S.tlasRoot; sp = 0;
+                } else active = false;
+            } else {
+                bB = bw;
+                active = false;
+            }
+        }
+        if (!__any(active)) break;
+        if (cur == RT_NONE) continue;
+        int budget = RT_DESCENT_CAP4;
+        while ((unsigned)cur < (unsigned)RT_REF_INSTANCE && budget-- > 0) {
+            const bool top = cur >= tlasBase;
+            const V3 ro = top ? org : lo, ri = top ? winv : linv;
+            Visit4 v;
+            visit4(S.nodes4 + cur, ro, ri, anyParW || __any(parL), tMin, bw.closest, v);
+            if (!__any(sp > RT_WIDE_LDS_LEVELS - 3)) {
+                lds_uint2* slot = wlds + sp * 64;
+                slot->x = (uint32_t)v.R3; slot->y = __float_as_uint(v.E3);
+                if (v.E3 < INFINITY) { ++sp; slot += 64; }
+                slot->x = (uint32_t)v.R2; slot->y = __float_as_uint(v.E2);
+                if (v.E2 < INFINITY) { ++sp; slot += 64; }
+                slot->x = (uint32_t)v.R1; slot->y = __float_as_uint(v.E1);
+                if (v.E1 < INFINITY) ++sp;
+            } else {
+                if (v.E3 < INFINITY) wide_push(wlds, wdeep, sp, v.R3, v.E3);
+                if (v.E2 < INFINITY) wide_push(wlds, wdeep, sp, v.R2, v.E2);
+                if (v.E1 < INFINITY) wide_push(wlds, wdeep, sp, v.R1, v.E1);
+            }
+            cur = v.R0;
+            if (!(v.E0 < INFINITY)) {
+                cur = RT_NONE;
+                while (sp > 0) {
+                    --sp;
+                    const uint2 e = wide_top(wlds, wdeep, sp);
+                    if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                }
+            }
+        }
+        if (cur >= RT_REF_INSTANCE && cur != RT_NONE) {
+            // into an object: its tree is walked by the ray in the object's space
+            obj = cur - RT_REF_INSTANCE;
+            ob = S.objects + obj;
+            lo = xform(ob->inv, org, 1.0f);
+            ld = normalize3(xform(ob->inv, dirN, 0.0f));
+            linv = ld;
+            parL = lean_inverse(ld, linv);
+            cur = ob->root;
+        } else if (cur < 0) {      // at a leaf (a lane whose descent was cut short goes on in the next round)
+            bool stop = false;
+            const float4* tp = reinterpret_cast<const float4*>(S.tris + ~cur);
+            float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            for (;;) {
+                tp += 3;
+                const float4 n0 = tp[0], n1 = tp[1], n2 = tp[2];
+                const int remaining = __float_as_int(t0.w);
+                if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, obj, bw) && ANYHIT) { stop = true; break; }
+                if (remaining <= 1) break;
+                t0 = n0; t1 = n1; t2 = n2;
+            }
+            cur = RT_NONE;
+            if (stop) sp = 0;
+            while (sp > 0) {
+                --sp;
+                const uint2 e = wide_top(wlds, wdeep, sp);
+                if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+            }
+        }
+    }
+}
+
 // GetHit for two rays per lane (see above). onA / onB: the lane has such a ray. ANYHIT: shadow rays,
 // leaf parents first, a ray stops at its first accepted hit.
-// NF: the scene holds rebuilt trees (DevScene::nearFirstBase set); false compiles the near-first handling out.
+// NF: 0 = the reference-order scene (near-first handling compiled out); 1 = the scene holds rebuilt two-child trees
+// (DevScene::nearFirstBase set); 2 = wide scene, four-child records, parents found box by box; 3 = wide scene with the
+// hierarchy over the parents (walk_tlas_pair).
 template <bool ANYHIT, int NF>
 __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V3 oA, V3 dA, bool onA, Best& bA, V3 oB, V3 dB, bool onB,
                                            Best& bB, float tMin, float tMax, uint2* stack)
@@ -1257,15 +1300,20 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
         const DevObject* ob = S.objects + i;   // wave-uniform address
         const bool liveA = onA && !(ANYHIT && bA.object >= 0), liveB = onB && !(ANYHIT && bB.object >= 0);
         if (ANYHIT && !__any(liveA || liveB)) break;
-        if (ob->root >= 0) {
+        if (NF == 3 && ob->root >= 0) {
+            // a wide scene keeps its BVH parents behind the leaf parents, in both orders: all of them in one walk
+            RT_SEC_BEGIN(secRun);
+            walk_tlas_pair<ANYHIT>(S, oA, dA, winvA, liveA, bA, oB, dB, winvB, liveB, bB, __any(parWA || parWB), tMin, stack);
+            RT_SEC_END(ANYHIT ? 6 : 3, secRun);
+            break;
+        }
+        if (NF != 3 && ob->root >= 0) {
             // consecutive BVH parents (up to 64): RT_RUN_MIN or more are walked lane by lane
             int count = permute ? S.runLenAny[pos] : S.runLen[pos];
             count = count < parentCount - pos ? count : parentCount - pos;
             if (count >= (NF == 2 ? 1 : RT_RUN_MIN)) {      // (four-child records are only walked by the run walker)
                 RT_SEC_BEGIN(secRun);
-                // a wide scene keeps its BVH parents behind the leaf parents, in both orders, in runs of 64 with a box hierarchy each
-                const DevBox4* tlas = NF == 2 && RT_TLAS_MIN <= 64 && count >= RT_TLAS_MIN ? S.tlas + ((pos - S.anyLeafCount) >> 6) * RT_RUN_QUARTETS : nullptr;
-                walk_run_pair<ANYHIT, NF>(S, permute, pos, count, oA, dA, winvA, liveA, bA, oB, dB, winvB, liveB, bB, __any(parWA || parWB), tMin, stack, tlas);
+                walk_run_pair<ANYHIT, NF>(S, permute, pos, count, oA, dA, winvA, liveA, bA, oB, dB, winvB, liveB, bB, __any(parWA || parWB), tMin, stack);
                 RT_SEC_END(ANYHIT ? 6 : 3, secRun);
                 pos += count - 1;
                 continue;
@@ -1309,7 +1357,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
         bool parL = lean_inverse(ld, linv);
         int cur = root, sp = 0;
         const bool nearFirst = NF == 1 && root >= S.nearFirstBase;   // wave-uniform: a rebuilt tree, nearer child first
-        if (NF == 2) continue;      // not reached: every BVH parent of a wide scene is in a run
+        if (NF >= 2) continue;      // not reached: every BVH parent of a wide scene is in a run or under the hierarchy
         for (;;) {
             int budget = RT_DESCENT_CAP;
             while ((unsigned)cur < (unsigned)RT_NONE && budget-- > 0) {
@@ -2933,8 +2981,11 @@ extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_p
     const dim3 grid((unsigned)blocks), block(64);
     // <true> knows rebuilt trees (near-first traversal), <false> has that handling compiled out
     // <2> walks four-child records (the wide twin of an order-free near-first scene)
-    const bool nf = S->nearFirstBase != 0x7fffffff, wide = S->nodes4 != nullptr;
-    if (wide && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<2>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    // <3> walks them from the hierarchy over the parents' boxes (wide scenes with many BVH parents)
+    const bool nf = S->nearFirstBase != 0x7fffffff, wide = S->nodes4 != nullptr, tlas = wide && S->tlasRoot != RT_REF_EMPTY;
+    if (tlas && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<3>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (tlas) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<3>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (wide && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<2>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
     else if (wide) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<2>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
     else if (nf && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<1>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
     else if (nf) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<1>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);

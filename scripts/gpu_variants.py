@@ -21,7 +21,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--one":
         r.render_frames(pc, 0, 1, 8); r.sync()
         best = 1e9
         for rep in range(3):
-            r.render_frames(pc, 0, 1, 16); r.sync()
+            r.render_frames(pc, 0, 1, 64); r.sync()
             best = min(best, r.last_render_ms()[1])
         out.append("p%d t%d %.3f %s" % (pipe, trav, best, hashlib.sha256(r.read_image(R.RT_IMAGE_ACCUM).tobytes()).hexdigest()[:8]))
     depth = [r.get_option(o) for o in (R.RT_INFO_STACK_DEPTH, R.RT_INFO_FAST_STACK_DEPTH)]

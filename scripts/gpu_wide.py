@@ -20,19 +20,22 @@ for cfg in configs:
     r.set_option(R.RT_OPT_PIPELINE, 3)
     r.set_option(R.RT_OPT_TRAVERSAL, 1)
     imgs, times = {}, {}
-    for wide in (0, 1):
+    for wide in (0, 2, 1):
         r.set_option(R.RT_OPT_WIDE_RECORDS, wide)
         r.clear_accumulation()
         r.render_frames(pc, 0, 1, 8); r.sync()
         imgs[wide] = r.read_image(R.RT_IMAGE_ACCUM).copy()
         best = 1e9
         for rep in range(3):
-            r.render_frames(pc, 8, 1, 16); r.sync()
+            r.render_frames(pc, 8, 1, 32); r.sync()
             best = min(best, r.last_render_ms()[1])
         times[wide] = best
     a, b = imgs[0].reshape(-1, 4), imgs[1].reshape(-1, 4)
     differ = int(np.any(a != b, axis=1).sum())
     tol = int(np.any(np.abs(a - b) > 1e-4 + 1e-4 * np.abs(a), axis=1).sum())
+    c, d = imgs[2].reshape(-1, 4), imgs[1].reshape(-1, 4)
+    print("config %s: four-child records with per-run box quartets %.3f ms/frame; with the hierarchy over the parents %.3f; pixels differing between those two %d (%d beyond tolerance)" % (
+        cfg, times[2], times[1], int(np.any(c != d, axis=1).sum()), int(np.any(np.abs(c - d) > 1e-4 + 1e-4 * np.abs(c), axis=1).sum())), flush=True)
     print("config %s %dx%d: two-child %.3f ms/frame, four-child %.3f ms/frame; pixels differing after 8 frames %d of %d (%d beyond 1e-4 tolerance); "
           "four-child records %d, stack need %d, two-child records %d depth %d" % (
               cfg, W, H, times[0], times[1], differ, a.shape[0], tol, r.get_option(R.RT_INFO_WIDE_RECORDS), r.get_option(R.RT_INFO_WIDE_STACK_NEED),
