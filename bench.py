@@ -100,21 +100,77 @@ def cpu_baseline(arrays, pc_bytes, W, H, seconds, threads, host_cpus):
             "msamples_per_s": pixels / dt / 1e6}
 
 
-def measured_traffic(kernel, config, traversal, frames_per_launch):
-    """HBM bytes per launch of `kernel` from profiles/hbm_traffic.json (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE,
-    separate --pmc passes, scripts/traffic.sh). An entry only counts when it was taken from the kernel
-    source this run uses (sha256 of rt_kernels.hip) in the same configuration; otherwise None."""
+KERNEL_SOURCES = ("rt_kernels.hip", "rt_team.inl", "rt_device.h", "rt_bvh.cpp", "rt_host.cpp")
+
+
+def kernel_source_hash():
+    """sha256 over the sources that decide what the dominant kernel does and touches: the kernels, the device
+    layout, the tree builder (its constants shape the trees) and the host code that lays the scene out."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "raytracer_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
+def measured_profile(kernel, config, traversal, frames_per_launch):
+    """-> (HBM bytes per launch, PMC summary dict) of `kernel` from profiles/hbm_traffic.json: rocprofv3
+    FETCH_SIZE x 2 + WRITE_SIZE (separate --pmc passes, scripts/traffic.sh) and, when the same entry carries
+    them, the issue statistics of the SQ passes (scripts/pmc_cfg.sh). An entry only counts when it was taken
+    from the sources this run uses (kernel_source_hash) in the same configuration; otherwise (None, None)."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    src = os.path.join(ROOT, "raytracer_amd", "csrc", "rt_kernels.hip")
     try:
-        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+        sha = kernel_source_hash()
         for e in json.load(open(path)).get("entries", []):
-            if (e.get("kernel"), str(e.get("config")), e.get("traversal"), e.get("frames_per_launch"), e.get("kernels_sha256")) == \
+            if (e.get("kernel"), str(e.get("config")), e.get("traversal"), e.get("frames_per_launch"), e.get("sources_sha256")) == \
                     (kernel, str(config), traversal, frames_per_launch, sha):
-                return e.get("bytes_per_launch")
+                return e.get("bytes_per_launch"), e.get("pmc")
     except Exception:
         pass
-    return None
+    return None, None
+
+
+def lavapipe_probe():
+    """The reference's own shader on a CPU Vulkan driver (lavapipe) would be the other CPU baseline. This only
+    looks whether a Vulkan loader and a software ICD exist on this machine and says what it found; it runs
+    nothing of the reference's."""
+    import ctypes, glob
+    found = {}
+    try:
+        ctypes.CDLL("libvulkan.so.1")
+        found["loader"] = "libvulkan.so.1"
+    except OSError as exc:
+        found["loader"] = None
+        found["loader_error"] = str(exc)
+    icds = []
+    for d in ("/usr/share/vulkan/icd.d", "/etc/vulkan/icd.d", "/usr/local/share/vulkan/icd.d"):
+        icds += sorted(glob.glob(os.path.join(d, "*.json")))
+    found["icd_files"] = icds
+    lvp = [f for f in icds if "lvp" in os.path.basename(f)]
+    spv = os.environ.get("RT_REFERENCE_SPV", "")
+    if found["loader"] and lvp and spv and os.path.exists(spv):
+        return {"status": "not run", "reason": "loader, lavapipe ICD and a SPIR-V file are present, but this build carries no Vulkan runner", **found}
+    missing = [what for what, ok in (("Vulkan loader (libvulkan.so.1)", found["loader"]), ("lavapipe ICD (lvp_icd*.json)", lvp),
+                                     ("the reference's SPIR-V (RT_REFERENCE_SPV; not shipped with this repository)", spv and os.path.exists(spv))) if not ok]
+    return {"status": "unavailable", "reason": "missing on this machine: " + "; ".join(missing), **found}
+
+
+def count_timed_work(config, traversal, frames):
+    """Box tests, triangle tests, GetHit calls and record fetches of the timed kernel's own traversal, counted by
+    the counter build of the same kernels (raytracer_amd/librt_amd_count.so) in a child process, untimed."""
+    import subprocess
+    lib = os.path.join(ROOT, "raytracer_amd", "librt_amd_count.so")
+    if not os.path.exists(lib):
+        return None
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "count_work.py"), str(config), str(traversal), str(frames)],
+                             capture_output=True, text=True, timeout=240)
+        if out.returncode != 0:
+            sys.stderr.write("bench.py: count_work.py failed: %s\n" % out.stderr[-400:])
+            return None
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as exc:
+        sys.stderr.write("bench.py: count_work.py: %s\n" % exc)
+        return None
 
 
 def main():
@@ -341,15 +397,36 @@ def main():
         flops_per_launch = (21.0 * node + 45.0 * tri) / launches
         alg_gbps = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         alg_tflops = flops_per_launch / (launch_ms * 1e-3) / 1e12
-        traffic = measured_traffic(kernel, args.config, args.traversal, group)
+        traffic, pmc = measured_profile(kernel, args.config, args.traversal, group)
         scene_bytes = sum(a.nbytes for a in arrays)
         # HBM is the bound only when the measured traffic says so (half the peak or more); without a measurement,
         # when the scene cannot sit in the caches (aggregate L2 8 x 4 MiB, 256 MiB memory-side cache behind it).
-        # Measured: configs 1-3 move 0.3 TB/s, the 198 MB scene of config 4 0.47 TB/s - every record fetch is a
-        # dependent access served by a cache, so all of them are bound by issue and latency.
+        # Measured: every configuration moves 0.3-0.8 TB/s - every record fetch is a dependent access served by
+        # a cache, so all of them are bound by issue and latency.
         traffic_rate = None if traffic is None else traffic / (launch_ms * 1e-3) / 1e9
         cache_resident = (traffic_rate < 0.5 * HBM_PEAK_GBPS) if traffic_rate is not None else (scene_bytes < 256 * 2 ** 20)
         spp_total = frames_rank * (world if not tile_split else 1)
+        # the work the TIMED kernel does (its own trees and order), counted by the counter build of the same kernels
+        # over the frames of one step (up to 64, scaled beyond); reference order: the counting kernel's figures are it
+        done = None
+        if world == 1 and pipeline == 3:
+            cf = min(frames_rank, 64)
+            cw = count_timed_work(args.config, args.traversal, cf)
+            if cw is not None:
+                k = frames_rank / float(cf) / launches
+                done = {"box_tests_per_launch": cw["box_tests"] * k, "triangle_tests_per_launch": cw["triangle_tests"] * k,
+                        "record_fetches_per_launch": cw["record_fetches"] * k, "rays_per_launch": cw["rays"] * k,
+                        "flops_per_launch": (21.0 * cw["box_tests"] + 45.0 * cw["triangle_tests"]) * k,
+                        "bytes_per_launch": (40.0 * cw["box_tests"] + 48.0 * cw["triangle_tests"]) * k + 48.0 * pixels_rank * frames_rank / launches,
+                        "counted_by": "raytracer_amd/librt_amd_count.so (the timed kernels with work counters), %d frames, untimed" % cf}
+                done["tflops"] = done["flops_per_launch"] / (launch_ms * 1e-3) / 1e12
+                done["gbps"] = done["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
+        ref_equiv = {"flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch, "tflops": alg_tflops, "gbps": alg_gbps,
+                     "frac_of_valu_peak": alg_tflops / VALU_PEAK_TFLOPS,
+                     "counted_by": "counting build of kernel 0: the reference's trees in the reference's order, i.e. the work the reference "
+                                   "shader would do for these rays (21 flops per box test, 45 per triangle test; 40 / 48 bytes)"}
+        ach_tflops = done["tflops"] if done else alg_tflops
+        ach_gbps = done["gbps"] if done else alg_gbps
         out = {
             "metric": "Mrays/s", "value": total_rays * args.steps / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -360,29 +437,36 @@ def main():
                                        "sample-split x%d (one all-reduce of the accumulation image)" % world) +
                                       (" inside librt_amd.so over RCCL" if native else " through torch.distributed/%s" % args.backend) if distributed else "single GPU",
                        "flavour": "%s traversal, %s arithmetic" % (names[args.traversal], "FMA-contracted" if args.fast else "strict binary32"),
+                       "library_default": "RT_OPT_TRAVERSAL 0 (reference order, bit-exact with the oracle): the other_flavour figures; near-first is opt-in and held to the tolerance bars",
                        "pipeline": pipeline},
             "ms_per_frame": ms_step / frames_rank, "msamples_per_s": W * H * spp_total * args.steps / dt / 1e6,
             "rays_per_step": total_rays,
             "rays_counted": "exact (counting kernel over every frame of the step)" if len(counted) == len(my_frames) else
                             "counting kernel over %d evenly spaced frames of %d, scaled" % (len(counted), len(my_frames)),
             # Served by the caches: the bound is vector-ALU issue and the latency of dependent record fetches, not
-            # HBM. `frac` is the achieved share of
-            # the FP32 vector peak in algorithmic flops (21 per box test, 45 per triangle test of the REFERENCE
-            # traversal); the algorithmic byte rate and the measured HBM traffic are given beside it.
+            # HBM. `achieved` / `frac`: algorithmic flops per second of the work the TIMED kernel does (21 per box
+            # test, 45 per triangle test, its own trees and order) against the FP32 vector peak; the work the
+            # reference's order would need for the same rays is given beside it, and so are the algorithmic byte
+            # rate (a work rate served by caches: no fraction of the HBM peak is formed from it) and the measured
+            # HBM traffic.
             "roofline": {"bound": "valu+latency" if cache_resident else "hbm",
-                         "achieved": alg_tflops if cache_resident else alg_gbps,
+                         "achieved": ach_tflops if cache_resident else ach_gbps,
                          "peak": VALU_PEAK_TFLOPS if cache_resident else HBM_PEAK_GBPS,
                          "unit": "TFLOP/s" if cache_resident else "GB/s",
-                         "frac": alg_tflops / VALU_PEAK_TFLOPS if cache_resident else alg_gbps / HBM_PEAK_GBPS,
+                         "frac": ach_tflops / VALU_PEAK_TFLOPS if cache_resident else ach_gbps / HBM_PEAK_GBPS,
+                         "counters": "timed kernel's own work" if done else "reference-order work (no count of the timed kernel's own work in this run)",
                          "traffic": traffic,
                          "traffic_gbps": traffic_rate,
+                         "traffic_frac_of_hbm_peak": None if traffic_rate is None else traffic_rate / HBM_PEAK_GBPS,
                          "kernel": kernel, "launch_ms": launch_ms, "frames_per_launch": group, "launches_per_step": launches,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_flops_per_launch": flops_per_launch,
+                         "work_done": done, "reference_work_equivalent": ref_equiv,
+                         "valu_busy": None if not pmc else pmc.get("valu_busy"), "lane_util": None if not pmc else pmc.get("lane_util"),
+                         "pmc": pmc,
                          "scene_bytes": scene_bytes,
-                         "hbm": {"achieved_gbps_algorithmic": alg_gbps, "peak_gbps": HBM_PEAK_GBPS, "frac_algorithmic": alg_gbps / HBM_PEAK_GBPS,
+                         "hbm": {"algorithmic_gbps": ach_gbps, "peak_gbps": HBM_PEAK_GBPS,
                                  "note": "algorithmic bytes (40 per box test, 48 per triangle test, 48 per pixel and frame) per second; "
-                                         "a work rate, not bytes that cross the HBM interface"},
-                         "valu": {"achieved_tflops": alg_tflops, "peak_tflops": VALU_PEAK_TFLOPS, "frac": alg_tflops / VALU_PEAK_TFLOPS}},
+                                         "a work rate that the caches serve, not bytes that cross the HBM interface - see traffic"}},
+            "lavapipe_baseline": lavapipe_probe() if world == 1 else None,
         }
         if exchange is not None:
             out["exchange"] = exchange

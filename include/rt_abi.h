@@ -136,7 +136,9 @@ enum {
     RT_INFO_FAST_OBJECTS = 103, RT_INFO_FAST_RECORDS = 104, RT_INFO_FAST_TRIANGLES = 105, RT_INFO_FAST_STACK_DEPTH = 106,
     /* Four-child records of the near-first scene (0 when the scene has none, see RT_OPT_WIDE_RECORDS) and the
      * traversal stack entries a lane can need while walking them. */
-    RT_INFO_WIDE_RECORDS = 107, RT_INFO_WIDE_STACK_NEED = 108
+    RT_INFO_WIDE_RECORDS = 107, RT_INFO_WIDE_STACK_NEED = 108,
+    /* Records of the hierarchy over the objects' boxes among them (0: the scene has none, see RT_OPT_WIDE_RECORDS). */
+    RT_INFO_TLAS_RECORDS = 109
 };
 
 /* ---- device context ------------------------------------------------------ */

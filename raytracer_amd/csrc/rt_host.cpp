@@ -984,11 +984,13 @@ int rt_get_option(rt_ctx* ctx, int option, int* value) try
     case RT_OPT_TRAVERSAL: *value = ctx->optTraversal; return RT_OK;
     case RT_OPT_SAH_MAX_LEAF: *value = ctx->sahMaxLeaf; return RT_OK;
     case RT_OPT_WIDE_RECORDS: *value = !ctx->optWide ? 0 : ctx->optTlas ? 1 : 2; return RT_OK;
-    case RT_INFO_WIDE_RECORDS: case RT_INFO_WIDE_STACK_NEED: {
+    case RT_INFO_WIDE_RECORDS: case RT_INFO_WIDE_STACK_NEED: case RT_INFO_TLAS_RECORDS: {
         if (!ctx->haveScene) { *value = 0; return RT_OK; }
         int rc = ensureFastScene(ctx);
         if (rc != RT_OK) return rc;
-        *value = !ctx->haveWide ? 0 : option == RT_INFO_WIDE_RECORDS ? (int)std::min<size_t>(ctx->wideNodeCount, 0x7fffffff) : ctx->wideScene.wideStackNeed;
+        *value = !ctx->haveWide ? 0 : option == RT_INFO_WIDE_RECORDS ? (int)std::min<size_t>(ctx->wideNodeCount, 0x7fffffff)
+               : option == RT_INFO_TLAS_RECORDS ? (ctx->wideScene.tlasRoot == RT_REF_EMPTY ? 0 : (int)ctx->wideNodeCount - ctx->wideScene.tlasBase)
+               : ctx->wideScene.wideStackNeed;
         return RT_OK;
     }
     case RT_INFO_FAST_OBJECTS: case RT_INFO_FAST_RECORDS: case RT_INFO_FAST_TRIANGLES: case RT_INFO_FAST_STACK_DEPTH: {

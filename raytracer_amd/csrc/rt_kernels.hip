@@ -41,6 +41,24 @@
 
 // Diagnostic build only (-DRT_SECTION_TIMERS): wave-level cycle counts per section of the lock-step
 // kernel, summed over all waves. No such code exists in the normal build.
+// Diagnostic build (-DRT_WORK_COUNTERS): the box tests, triangle tests, GetHit calls and record fetches the two-
+// samples-per-lane kernels really perform, whichever trees and order they walk (the counting build of kernel 0
+// only knows the reference's). Every lane adds into its own LDS word; a wave adds its sums to g_workCounters
+// when it ends; rt_debug_work_counters() reads and clears them.
+#ifdef RT_WORK_COUNTERS
+__device__ unsigned long long g_workCounters[4];     // 0 box tests, 1 triangle tests, 2 GetHit calls, 3 record fetches
+__device__ __noinline__ unsigned* rt_work_lds() { __shared__ unsigned a[4 * 64]; return a; }
+#define RT_WORK(k, n) do { rt_work_lds()[(k) * 64 + (threadIdx.x & 63)] += (unsigned)(n); } while (0)
+#define RT_WORK_BEGIN() do { unsigned* a_ = rt_work_lds(); for (int k_ = 0; k_ < 4; ++k_) a_[k_ * 64 + (threadIdx.x & 63)] = 0; } while (0)
+#define RT_WORK_END() do { const unsigned* a_ = rt_work_lds(); \
+        if ((int)threadIdx.x == __ffsll((long long)__ballot(true)) - 1) \
+            for (int k_ = 0; k_ < 4; ++k_) { unsigned long long s_ = 0; for (int l_ = 0; l_ < 64; ++l_) s_ += a_[k_ * 64 + l_]; atomicAdd(&g_workCounters[k_], s_); } } while (0)
+#else
+#define RT_WORK(k, n) do { } while (0)
+#define RT_WORK_BEGIN() do { } while (0)
+#define RT_WORK_END() do { } while (0)
+#endif
+
 #ifdef RT_SECTION_TIMERS
 __device__ unsigned long long g_sectionCycles[8];
 __device__ __noinline__ unsigned* rt_sec_lds() { __shared__ unsigned a[8]; return a; }
@@ -330,6 +348,8 @@ __device__ __forceinline__ void visit_node(const DevScene& S, int cur, V3 o, V3 
 {
     if (anyParallel) node_boxes<true>(S.nodes + cur, o, inv, tMin, r);
     else node_boxes<false>(S.nodes + cur, o, inv, tMin, r);
+    RT_WORK(0, (r.refs.x != RT_REF_ABSENT) + (r.refs.y != RT_REF_ABSENT));
+    RT_WORK(3, 1);
 }
 
 // One visit of a four-child record (DevNode4): four slab tests, the children that the ray can enter in front of
@@ -368,6 +388,8 @@ __device__ __forceinline__ void visit4(const DevNode4* node, V3 o, V3 inv, bool 
     const float4* np = reinterpret_cast<const float4*>(node);
     const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
     const int4 refs = *reinterpret_cast<const int4*>(np + 6);
+    RT_WORK(0, (refs.x != RT_REF_EMPTY) + (refs.y != RT_REF_EMPTY) + (refs.z != RT_REF_EMPTY) + (refs.w != RT_REF_EMPTY));
+    RT_WORK(3, 1);
     const f32x2 ox = { o.x, o.x }, oy = { o.y, o.y }, oz = { o.z, o.z };
     const f32x2 ix = { inv.x, inv.x }, iy = { inv.y, inv.y }, iz = { inv.z, inv.z };
     const f32x2 ax0 = (f32x2{ lx.x, lx.y } - ox) * ix, ax1 = (f32x2{ hx.x, hx.y } - ox) * ix;
@@ -450,6 +472,7 @@ struct HitRec { V3 point, normal; int matIndex; float t; bool frontFace; bool hi
 __device__ __forceinline__ bool triangle_hit(float4 t0, float4 t1, float4 t2, V3 lo, V3 ld, const float* fwd, V3 org, V3 dirN,
                                              float tMin, int objectIndex, Best& best)
 {
+    RT_WORK(1, 1);
     V3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t1.x, t1.y, t1.z), e2 = mk(t2.x, t2.y, t2.z);
     V3 h = cross3(ld, e2);
     float det = dot3(e1, h);
@@ -1016,6 +1039,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
         const DevObject* o2 = S.objects + j;     // wave-uniform address
         const V3 bmn = ld3(o2->bmin), bmx = ld3(o2->bmax);
         float E;
+        RT_WORK(0, (liveA ? 1 : 0) + (liveB ? 1 : 0));
         if (liveA && (anyPar ? lean_box<true>(oA, winvA, bmn, bmx, tMin, E) : lean_box<false>(oA, winvA, bmn, bmx, tMin, E)) && (bA.closest > E))
             mA |= 1ull << k;
         if (liveB && (anyPar ? lean_box<true>(oB, winvB, bmn, bmx, tMin, E) : lean_box<false>(oB, winvB, bmn, bmx, tMin, E)) && (bB.closest > E))
@@ -1057,6 +1081,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
                 const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
                 float E;
                 bool ok = (anyPar ? lean_box<true>(org, winv, bmn, bmx, tMin, E) : lean_box<false>(org, winv, bmn, bmx, tMin, E)) && (bw.closest > E);
+                RT_WORK(0, 1);
                 if (!NF && ok) ok = !(distance_to_aabb(org, bmn, bmx) > bw.closest);
                 if (ok) {
                     lo = xform(ob->inv, org, 1.0f);
@@ -1289,6 +1314,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
                                            Best& bB, float tMin, float tMax, uint2* stack)
 {
     RT_SEC_BEGIN(secTrace);
+    RT_WORK(2, (onA ? 1 : 0) + (onB ? 1 : 0));
     best_reset(bA, tMax);
     best_reset(bB, tMax);
     V3 winvA, winvB;
@@ -1319,6 +1345,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
                 continue;
             }
         }
+        RT_WORK(0, (liveA ? 1 : 0) + (liveB ? 1 : 0));
         const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
         float E;
         bool okA = liveA && (__any(parWA) ? lean_box<true>(oA, winvA, bmn, bmx, tMin, E) : lean_box<false>(oA, winvA, bmn, bmx, tMin, E)) &&
@@ -1635,6 +1662,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
     if (lane < 8) rt_sec_lds()[lane] = 0;
 #endif
     RT_SEC_BEGIN(secKernel);
+    RT_WORK_BEGIN();
 
     const int wavesX = L.tileSize >> 3;
     const int wavesPerTile = wavesX * wavesX;
@@ -1711,6 +1739,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
     float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(nc.x, nc.y, nc.z, 1.0f);
     avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
     out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
+    RT_WORK_END();
 #ifdef RT_SECTION_TIMERS
     if (lane == __ffsll((long long)__ballot(true)) - 1) {
         unsigned* a = rt_sec_lds();
@@ -1736,6 +1765,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
     if (lane < 8) rt_sec_lds()[lane] = 0;
 #endif
     RT_SEC_BEGIN(secKernel);
+    RT_WORK_BEGIN();
 
     const int wavesX = L.tileSize >> 3;
     const int wavesPerTile = PIX ? wavesX * (wavesX >> 1) : wavesX * wavesX;
@@ -1843,6 +1873,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
         avgB.x *= accumulationMultiplier; avgB.y *= accumulationMultiplier; avgB.z *= accumulationMultiplier;
         out[idxq[1]] = make_float4(linear_to_gamma(avgB.x), linear_to_gamma(avgB.y), linear_to_gamma(avgB.z), avgB.w);
     }
+    RT_WORK_END();
 #ifdef RT_SECTION_TIMERS
     if (lane == __ffsll((long long)__ballot(true)) - 1) {
         unsigned* a = rt_sec_lds();
@@ -2946,6 +2977,17 @@ extern "C" int rt_debug_sections(unsigned long long out[8])
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sectionCycles), sizeof(zero)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_sectionCycles), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
+#if defined(RT_WORK_COUNTERS) && defined(RT_FLAVOUR_STRICT)
+// reads and clears the work counters of the strict flavour's two-samples-per-lane kernels (the device must be idle)
+extern "C" int rt_debug_work_counters(unsigned long long out[4])
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_workCounters), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long zero[4] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_workCounters), zero, sizeof(zero)) != hipSuccess) return -1;
     return 0;
 }
 #endif

@@ -260,3 +260,56 @@ def test_more_than_64_bvh_parents_in_a_row(R):
             assert ok >= 0.995 and same >= 0.99, (pipeline, same, ok)
     finally:
         r.close()
+
+
+def test_hierarchy_over_the_parents(R):
+    """23 objects that own a tree, none scaled below 1 (so that hits do not depend on the visiting order), a floor
+    and a back wall: pipeline 3 walks them from the hierarchy over their world boxes (RT_OPT_WIDE_RECORDS 1).
+    Against the oracle within the bars, in launches of several frames and in single-frame dispatches, and
+    against the same four-child records without the hierarchy (RT_OPT_WIDE_RECORDS 2) and two-child records (0)."""
+    materials = [scenes.mat((0.6, 0.6, 0.6)), scenes.mat((0.8, 0.3, 0.2)), scenes.mat((0.9, 0.9, 0.9), smoothness=1.0, fuzziness=0.2),
+                 scenes.mat((1, 1, 1), ior=1.5), scenes.mat((0.2, 0.5, 0.8))]
+    objects = []
+    for k in range(23):
+        gx, gy, gz = k % 4, (k // 4) % 3, k // 12
+        model = ("cube.obj", "smooth_sphere.obj", "icosphere.obj", "teapot.obj")[k % 4]
+        s = (1.0, 1.3, 1.0, 1.0)[k % 4]
+        objects.append((model, (-6.0 + 4.0 * gx + 0.7 * gz, 1.2 + 3.0 * gy, -4.0 - 5.0 * gz), (0, 31 * k, 7 * k), (s, s, s), 1 + k % 4))
+    objects.append(("flat_quad.obj", (0, 0, 0), (0, 0, 0), (40, 40, 40), 0))
+    objects.append(("flat_quad.obj", (0, 0, -16), (90, 0, 0), (40, 40, 40), 0))
+    arrays = scenes.build_oracle(materials, objects).bindings()
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(arrays)
+        assert r.get_option(R.RT_INFO_FAST_OBJECTS) == 23
+        assert r.get_option(R.RT_INFO_TLAS_RECORDS) > 0
+        W, H = 256, 144
+        opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 5.0, 11.0), look=(0.0, -0.12, -1.0), fov=65.0, maxBounces=4)
+        want_acc, want_out = oracle(arrays, opc, [0, 1, 2], W, H)
+        images = {}
+        for wide in (1, 2, 0):
+            r.set_option(R.RT_OPT_WIDE_RECORDS, wide)
+            assert (r.get_option(R.RT_INFO_TLAS_RECORDS) > 0) == (wide != 2)      # (0 only stops the kernels from using the wide scene)
+            acc, out = render(R, r, opc, [0, 1, 2], W, H, 1, 3)
+            same, ok = shares(acc, want_acc)
+            assert ok >= 0.995 and same >= 0.99, (wide, same, ok)
+            images[wide] = acc
+        assert shares(images[1], images[2])[0] >= 0.999 and shares(images[1], images[0])[0] >= 0.999
+        # the reference's interactive dispatch: one frame per launch, two pixels per lane
+        r.set_option(R.RT_OPT_WIDE_RECORDS, 1)
+        r.set_option(R.RT_OPT_PIPELINE, 3)
+        r.set_option(R.RT_OPT_TRAVERSAL, 1)
+        r.clear_accumulation()
+        for f in (0, 1, 2):
+            opc["frame"] = f
+            r.render_frame(to_pc(R, opc))
+        same, ok = shares(r.read_image(R.RT_IMAGE_ACCUM), want_acc)
+        assert ok >= 0.995 and same >= 0.99, (same, ok)
+        # the sun from another side: shadow rays take the same walk
+        opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 5.0, 11.0), look=(0.0, -0.12, -1.0), fov=65.0, maxBounces=2, sunDirection=(0.6, -0.5, -0.4))
+        want_acc, want_out = oracle(arrays, opc, [0, 1], W, H)
+        acc, out = render(R, r, opc, [0, 1], W, H, 1, 3)
+        same, ok = shares(acc, want_acc)
+        assert ok >= 0.995 and same >= 0.99, (same, ok)
+    finally:
+        r.close()
