@@ -79,8 +79,10 @@ struct DevTri {
 
 static_assert(sizeof(DevNode4) == 128, "DevNode4: one 128-byte line per record");
 
-#define RT_WIDE_LDS_LEVELS 16     /* traversal-stack entries of the four-child walk kept in LDS */
-#define RT_WIDE_DEEP_LEVELS 48    /* further entries, in the lane's private memory */
+#ifndef RT_WIDE_LDS_LEVELS
+#define RT_WIDE_LDS_LEVELS 8      /* traversal-stack entries of the four-child walk kept in LDS (16, 12 and 8 measured: same time) */
+#endif
+#define RT_WIDE_DEEP_LEVELS 56    /* further entries, in the lane's private memory */
 
 struct DevNrm {
     float n0[4], n1[4], n2[4];

@@ -802,9 +802,11 @@ __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta)
 }
 
 // raytrace.comp:623-668
+// UNIT: rayDir is normalize3() of the ray's direction already (the value this function would compute itself)
+template <bool UNIT = false>
 __device__ __forceinline__ V3 environment_colour(const rt_push_constants& pc, V3 rayDir)
 {
-    V3 unitDir = normalize3(rayDir);
+    V3 unitDir = UNIT ? rayDir : normalize3(rayDir);
     V3 sunDir = normalize3(ld3(pc.sunDirection));
     float sunDotUp = dot3(-sunDir, mk(0.0f, 1.0f, 0.0f));
     const V3 dayZenith = mk(0.5f, 0.7f, 1.0f), dayHorizon = mk(1.0f, 1.0f, 1.0f), sunrise = mk(1.0f, 0.4f, 0.2f);
@@ -887,7 +889,9 @@ __device__ __forceinline__ ScatterDraws scatter_draws(uint32_t seed)
 }
 
 // MaterialScatter + DielectricScatter, raytrace.comp:371-423. `seed` by value. pre: the sample's two unit
-// vectors drawn ahead (scatter_draws), or null to draw them here.
+// vectors drawn ahead (scatter_draws), or null to draw them here. UNIT: rayDir is normalize3() of the ray's
+// direction already.
+template <bool UNIT = false>
 __device__ __forceinline__ void material_scatter(const DevMaterial& m, V3 rayDir, const HitRec& rec, uint32_t seed,
                                                  V3& attenuation, Ray& scattered, const ScatterDraws* pre = nullptr)
 {
@@ -898,7 +902,7 @@ __device__ __forceinline__ void material_scatter(const DevMaterial& m, V3 rayDir
         V3 e = mk(rt_expf(-ab.x * rec.t), rt_expf(-ab.y * rec.t), rt_expf(-ab.z * rec.t));
         attenuation = ld3(m.colour) * e;
         float etai = rec.frontFace ? (1.0f / refIdx) : refIdx;
-        V3 unit = normalize3(rayDir);
+        V3 unit = UNIT ? rayDir : normalize3(rayDir);
         float cosTheta = gmin(dot3(-unit, rec.normal), 1.0f);
         float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
         bool cannotRefract = etai * sinTheta > 1.0f;
@@ -913,7 +917,7 @@ __device__ __forceinline__ void material_scatter(const DevMaterial& m, V3 rayDir
     }
     const float EPSILON = 1e-4f;
     if (scatterOrReflect < m.smoothness) {
-        V3 reflected = reflect3(normalize3(rayDir), rec.normal);
+        V3 reflected = reflect3(UNIT ? rayDir : normalize3(rayDir), rec.normal);
         V3 fuzz;
         if (pre) fuzz = dot3(pre->metal, rec.normal) > 0.0f ? pre->metal : -pre->metal;     // Random.glsl:83-87
         else fuzz = random_on_hemisphere(rec.normal, seed);
@@ -1002,7 +1006,8 @@ __device__ __forceinline__ V3 ray_colour(const DevScene& S, const rt_push_consta
 // pixel in sequence order, so the image is the one the one-sample kernel renders.
 
 struct PathState {
-    V3 o, d;              // next regular ray (d as the shader keeps it)
+    V3 o, d;              // next regular ray; d = normalize(direction as the shader keeps it), the only form it is ever used in
+                          // (GetHit raytrace.comp:451, GetEnvironmentColour :626, MaterialScatter :376,:402)
     V3 throughput, result;
     V3 sun;               // sun term of the last hit, added when its shadow ray comes back unblocked
     V3 so;                // origin of that shadow ray
@@ -1010,6 +1015,22 @@ struct PathState {
     bool alive;           // wants a regular GetHit
     bool shadow;          // wants a shadow GetHit
 };
+
+// Path state that the wide kernels (NF >= 2) keep in LDS rather than in registers: a sample's result, throughput and
+// its two scatter vectors are only touched between GetHit calls, whose own loops need every register that four
+// waves per SIMD leave a wave - held in registers they are pushed out to private memory around every call, and
+// private memory is device memory: the spill areas of an XCD's 512 waves do not fit its L2, so that traffic
+// reaches HBM (measured on the default scene at 2560x1369: 6.2 GB written per launch of 8 frames with the state in
+// registers, of 7.4 GB before the path kept its direction in one form only). Laid out [dword][lane] behind the
+// traversal stack, 12 dwords per path: result, throughput, Lambert vector, metal vector.
+#define RT_RES_DWORDS 24
+#ifndef RT_RES_SET
+#define RT_RES_SET 6      /* which fields live in LDS: 1 result, 2 throughput, 4 scatter vectors (measured, ms per frame / GB written per
+                             launch on the default scene: 7: 2.075 / 1.96; 6: 1.985 / 3.08; 5: 2.04 / 3.30; 4: 2.02 / 4.13; none: 2.13 / 6.23) */
+#endif
+enum { RES_RESULT = 0, RES_THROUGHPUT = 3, RES_LAMBERT = 6, RES_METAL = 9, RES_PER_PATH = 12 };
+__device__ __forceinline__ V3 res_ld(const float* res, int k) { return mk(res[k * 64], res[(k + 1) * 64], res[(k + 2) * 64]); }
+__device__ __forceinline__ void res_st(float* res, int k, V3 v) { res[k * 64] = v.x; res[(k + 1) * 64] = v.y; res[(k + 2) * 64] = v.z; }
 
 __device__ __forceinline__ void best_reset(Best& b, float tMax)
 {
@@ -1454,21 +1475,28 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
 // The part of RayColour's loop body between two GetHit calls (raytrace.comp:701-766) for one path:
 // takes the regular hit, adds sky / emission, ends the path or prepares the shadow ray (sun term kept
 // aside until the shadow ray's answer is in) and the next regular ray.
-__device__ __forceinline__ void pair_shade(const DevScene& S, const rt_push_constants& pc, PathState& p, V3 dirN, const Best& best, uint32_t seed)
+// RES: result, throughput and the scatter vectors of the path live in LDS at `res` (see above); the fields of `p`
+// are then only scratch.
+template <bool RES>
+__device__ __forceinline__ void pair_shade(const DevScene& S, const rt_push_constants& pc, PathState& p, V3 dirN, const Best& best, uint32_t seed, float* res)
 {
     p.shadow = false;
     if (!p.alive) return;
     HitRec rec;
     finish_hit(S, p.o, dirN, best, rec);
+    if (RES && (RT_RES_SET & 2)) p.throughput = res_ld(res, RES_THROUGHPUT);
     if (!rec.hit) {
-        p.result = p.result + p.throughput * environment_colour(pc, p.d);
+        const V3 sky = p.throughput * environment_colour<true>(pc, p.d);
+        if (RES && (RT_RES_SET & 1)) res_st(res, RES_RESULT, res_ld(res, RES_RESULT) + sky);
+        else p.result = p.result + sky;
         p.alive = false;
         return;
     }
     if (!rec.frontFace) { p.alive = false; return; }
     DevMaterial m = load_material(S, rec.matIndex);
     V3 emitted = ld3(m.colour) * m.emission;
-    p.result = p.result + p.throughput * emitted;
+    if (RES && (RT_RES_SET & 1)) res_st(res, RES_RESULT, res_ld(res, RES_RESULT) + p.throughput * emitted);
+    else p.result = p.result + p.throughput * emitted;
     if (m.emission > 0.0f) { p.alive = false; return; }
     V3 negSun = -ld3(pc.sunDirection);
     float nDotL = gmax(dot3(rec.normal, negSun), 0.0f);
@@ -1483,10 +1511,12 @@ __device__ __forceinline__ void pair_shade(const DevScene& S, const rt_push_cons
     }
     V3 attenuation;
     Ray scattered;
-    material_scatter(m, p.d, rec, seed, attenuation, scattered, &p.draws);
+    if (RES && (RT_RES_SET & 4)) { p.draws.lambert = res_ld(res, RES_LAMBERT); p.draws.metal = res_ld(res, RES_METAL); }
+    material_scatter<true>(m, p.d, rec, seed, attenuation, scattered, &p.draws);
     p.throughput = p.throughput * attenuation;
+    if (RES && (RT_RES_SET & 2)) res_st(res, RES_THROUGHPUT, p.throughput);
     p.o = scattered.o;
-    p.d = scattered.d;
+    p.d = normalize3(scattered.d);
 }
 
 // SeedFromCoords of entry m of a pixel's sample sequence (frame m / rpp of the launch, sample m % rpp)
@@ -1663,6 +1693,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
 #endif
     RT_SEC_BEGIN(secKernel);
     RT_WORK_BEGIN();
+    constexpr bool RES = NF >= 2;
+    float* const res = reinterpret_cast<float*>(stackMem + S.stackDepth * 64) + lane;      // (wide kernels: LDS-resident path state)
 
     const int wavesX = L.tileSize >> 3;
     const int wavesPerTile = wavesX * wavesX;
@@ -1683,7 +1715,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
     const float raysPerPixelRatio = 1.0f / (float)rpp;
     const V3 sunDirN = normalize3(-ld3(pc.sunDirection));
     V3 nc = mk(0.0f, 0.0f, 0.0f);
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // the frame's running sum waits in LDS while the lane's samples are traced, in the (otherwise unused) result slot of path 0
+    constexpr bool NC_LDS = RES && !(RT_RES_SET & 1);
+    if (NC_LDS) res_st(res, RES_RESULT, nc);
 
     for (int n = 0; n < total; n += 2) {
         PathState P[2];
@@ -1699,44 +1733,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             p.so = mk(0.0f, 0.0f, 0.0f);
             const uint32_t seed = pair_seed(pc, L, x, y, m, rpp);
             Ray ray = get_ray(pc, x, y, seed);
-            p.o = ray.o; p.d = ray.d;
+            p.o = ray.o; p.d = normalize3(ray.d);
             p.draws = scatter_draws(seed);
+            if (RES) {
+                float* const r = res + q * RES_PER_PATH * 64;
+                if (RT_RES_SET & 1) res_st(r, RES_RESULT, p.result);
+                if (RT_RES_SET & 2) res_st(r, RES_THROUGHPUT, p.throughput);
+                if (RT_RES_SET & 4) { res_st(r, RES_LAMBERT, p.draws.lambert); res_st(r, RES_METAL, p.draws.metal); }
+            }
         }
         for (int bounce = 0; bounce < bounces; ++bounce) {
             if (!(P[0].alive || P[1].alive)) break;
-            const V3 dirA = normalize3(P[0].d), dirB = normalize3(P[1].d);
+            const V3 dirA = P[0].d, dirB = P[1].d;
             Best bA, bB;
             trace_pair<false, NF>(S, pc.parentBVHCount, P[0].o, dirA, P[0].alive, bA, P[1].o, dirB, P[1].alive, bB, 0.001f, 1e20f, stack);
             // (the seed of a sample is recomputed where it is needed rather than carried through the walks)
             RT_SEC_BEGIN(secShade);
-            pair_shade(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, y, n, rpp));
-            pair_shade(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, y, n + 1, rpp));
+            pair_shade<RES>(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, y, n, rpp), res);
+            pair_shade<RES>(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, y, n + 1, rpp), res + RES_PER_PATH * 64);
             RT_SEC_END(4, secShade);
             if (P[0].shadow || P[1].shadow) {
                 trace_pair<true, NF>(S, pc.parentBVHCount, P[0].so, sunDirN, P[0].shadow, bA, P[1].so, sunDirN, P[1].shadow, bB, 0.001f, 1e20f, stack);
-                if (P[0].shadow && bA.object < 0) P[0].result = P[0].result + P[0].sun;
-                if (P[1].shadow && bB.object < 0) P[1].result = P[1].result + P[1].sun;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (!(P[q].shadow && (q ? bB : bA).object < 0)) continue;
+                    if (RES && (RT_RES_SET & 1)) res_st(res + q * RES_PER_PATH * 64, RES_RESULT, res_ld(res + q * RES_PER_PATH * 64, RES_RESULT) + P[q].sun);
+                    else P[q].result = P[q].result + P[q].sun;
+                }
             }
         }
+        if (NC_LDS) nc = res_ld(res, RES_RESULT);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int m = n + q;
             if (m >= total) break;
-            nc = nc + P[q].result;
+            nc = nc + (RES && (RT_RES_SET & 1) ? res_ld(res + q * RES_PER_PATH * 64, RES_RESULT) : P[q].result);
             const int fr = m / rpp, i = m - fr * rpp;
             if (i == rpp - 1) {
                 // end of a frame: the pixel goes through memory as in the one-sample kernel
-                acc = accum[idx];
+                float4 acc = accum[idx];
                 nc = nc * raysPerPixelRatio;
                 acc.x += nc.x; acc.y += nc.y; acc.z += nc.z;
                 accum[idx] = acc;
                 if (m + 1 < total) nc = mk(0.0f, 0.0f, 0.0f);
             }
         }
+        if (NC_LDS) res_st(res, RES_RESULT, nc);
     }
+    if (NC_LDS) nc = res_ld(res, RES_RESULT);
     const int lastFrame = pc.frame + (L.frames - 1) * L.frameStride;
     const float accumulationMultiplier = pc.accumulateFrames == 1 ? 1.0f / (float)(lastFrame + 1) : 1.0f;
-    float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(nc.x, nc.y, nc.z, 1.0f);
+    // (the pixel as this lane stored it after its last sample: read back rather than kept in registers across the samples)
+    float4 avg = pc.accumulateFrames == 1 ? accum[idx] : make_float4(nc.x, nc.y, nc.z, 1.0f);
     avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
     out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
     RT_WORK_END();
@@ -1766,6 +1814,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
 #endif
     RT_SEC_BEGIN(secKernel);
     RT_WORK_BEGIN();
+    constexpr bool RES = NF >= 2;
+    float* const res = reinterpret_cast<float*>(stackMem + S.stackDepth * 64) + lane;      // (wide kernels: LDS-resident path state)
 
     const int wavesX = L.tileSize >> 3;
     const int wavesPerTile = PIX ? wavesX * (wavesX >> 1) : wavesX * wavesX;
@@ -1808,30 +1858,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             p.so = mk(0.0f, 0.0f, 0.0f);
             const uint32_t seed = pair_seed(pc, L, x, yq[q], m, rpp);
             Ray ray = get_ray(pc, x, yq[q], seed);
-            p.o = ray.o; p.d = ray.d;
+            p.o = ray.o; p.d = normalize3(ray.d);
             p.draws = scatter_draws(seed);
+            if (RES) {
+                float* const r = res + q * RES_PER_PATH * 64;
+                if (RT_RES_SET & 1) res_st(r, RES_RESULT, p.result);
+                if (RT_RES_SET & 2) res_st(r, RES_THROUGHPUT, p.throughput);
+                if (RT_RES_SET & 4) { res_st(r, RES_LAMBERT, p.draws.lambert); res_st(r, RES_METAL, p.draws.metal); }
+            }
         }
         for (int bounce = 0; bounce < bounces; ++bounce) {
             if (!(P[0].alive || P[1].alive)) break;
-            const V3 dirA = normalize3(P[0].d), dirB = normalize3(P[1].d);
+            const V3 dirA = P[0].d, dirB = P[1].d;
             Best bA, bB;
             trace_pair<false, NF>(S, pc.parentBVHCount, P[0].o, dirA, P[0].alive, bA, P[1].o, dirB, P[1].alive, bB, 0.001f, 1e20f, stack);
             // (the seed of a sample is recomputed where it is needed rather than carried through the walks)
             RT_SEC_BEGIN(secShade);
-            pair_shade(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, yq[0], mq[0], rpp));
-            pair_shade(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, yq[1], mq[1], rpp));
+            pair_shade<RES>(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, yq[0], mq[0], rpp), res);
+            pair_shade<RES>(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, yq[1], mq[1], rpp), res + RES_PER_PATH * 64);
             RT_SEC_END(4, secShade);
             if (P[0].shadow || P[1].shadow) {
                 trace_pair<true, NF>(S, pc.parentBVHCount, P[0].so, sunDirN, P[0].shadow, bA, P[1].so, sunDirN, P[1].shadow, bB, 0.001f, 1e20f, stack);
-                if (P[0].shadow && bA.object < 0) P[0].result = P[0].result + P[0].sun;
-                if (P[1].shadow && bB.object < 0) P[1].result = P[1].result + P[1].sun;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (!(P[q].shadow && (q ? bB : bA).object < 0)) continue;
+                    if (RES && (RT_RES_SET & 1)) res_st(res + q * RES_PER_PATH * 64, RES_RESULT, res_ld(res + q * RES_PER_PATH * 64, RES_RESULT) + P[q].sun);
+                    else P[q].result = P[q].result + P[q].sun;
+                }
             }
         }
         if (PIX) {
             // one sample of each of the two pixels
             const int fr = n / rpp, i = n - fr * rpp;
-            nc = nc + P[0].result;
-            ncB = ncB + P[1].result;
+            nc = nc + (RES && (RT_RES_SET & 1) ? res_ld(res, RES_RESULT) : P[0].result);
+            ncB = ncB + (RES && (RT_RES_SET & 1) ? res_ld(res + RES_PER_PATH * 64, RES_RESULT) : P[1].result);
             if (i == rpp - 1) {
                 acc = accum[idxq[0]];
                 nc = nc * raysPerPixelRatio;
@@ -1850,7 +1910,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             for (int q = 0; q < 2; ++q) {
                 const int m = n + q;
                 if (m >= total) break;
-                nc = nc + P[q].result;
+                nc = nc + (RES && (RT_RES_SET & 1) ? res_ld(res + q * RES_PER_PATH * 64, RES_RESULT) : P[q].result);
                 const int fr = m / rpp, i = m - fr * rpp;
                 if (i == rpp - 1) {
                     // end of a frame: the pixel goes through memory as in the one-sample kernel
@@ -3019,7 +3079,11 @@ extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_p
     const long long blocks = (long long)L->ownedTiles * wavesX * (pixelPairs ? wavesX / 2 : wavesX);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
+    // wide scenes: the walk keeps RT_WIDE_LDS_LEVELS entries of a lane's stack in LDS (deeper ones in private memory), the LDS-resident path state behind them
+    DevScene scene = *S;
+    if (scene.nodes4 != nullptr && scene.stackDepth > RT_WIDE_LDS_LEVELS) scene.stackDepth = RT_WIDE_LDS_LEVELS;
+    S = &scene;
+    const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2) + (S->nodes4 != nullptr ? (size_t)RT_RES_DWORDS * 64 * sizeof(float) : 0);
     const dim3 grid((unsigned)blocks), block(64);
     // <true> knows rebuilt trees (near-first traversal), <false> has that handling compiled out
     // <2> walks four-child records (the wide twin of an order-free near-first scene)

@@ -3,7 +3,7 @@
 # HBM traffic per launch of the dominant kernel: rocprofv3 FETCH_SIZE and WRITE_SIZE in separate --pmc
 # passes (they do not fit one pass), FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request). Writes
 # gpurun_out/traffic_<config>_<traversal>.json, an entry for profiles/hbm_traffic.json that carries the
-# sha256 of rt_kernels.hip, so that bench.py only uses it for the kernel source it was measured on.
+# sha256 over the kernel, layout, tree-builder and host sources, so that bench.py only uses it for the sources it was measured on.
 CFG=$1; TRAV=$2; FRAMES=${3:-0}
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic_${CFG}_${TRAV}
@@ -26,14 +26,17 @@ def collect(sub, counter):
 fetch, write = collect("fetch", "FETCH_SIZE"), collect("write", "WRITE_SIZE")
 frames_line = [l for l in open(os.path.join(out, "fetch.log")).read().splitlines() if "frames per launch" in l][-1].strip()
 fpl = int(frames_line.split(",")[-1].split()[0])
-sha = hashlib.sha256(open(os.path.join(root, "raytracer_amd/csrc/rt_kernels.hip"), "rb").read()).hexdigest()
+h = hashlib.sha256()
+for name in ("rt_kernels.hip", "rt_team.inl", "rt_device.h", "rt_bvh.cpp", "rt_host.cpp"):      # bench.py: kernel_source_hash()
+    h.update(open(os.path.join(root, "raytracer_amd/csrc", name), "rb").read())
+sha = h.hexdigest()
 entries = []
 for k in fetch:
     # the first dispatch is the warm-up launch; full launches of the timed call follow
     f = fetch[k][1:] or fetch[k]; w = write.get(k, [0.0])[1:] or write.get(k, [0.0])
     full_f = max(f); full_w = max(w)           # a ragged last launch holds fewer frames
     name = k.split("<")[0]
-    entries.append({"kernel": name, "config": cfg, "traversal": trav, "frames_per_launch": fpl, "kernels_sha256": sha,
+    entries.append({"kernel": name, "config": cfg, "traversal": trav, "frames_per_launch": fpl, "sources_sha256": sha,
                     "fetch_size_kb": full_f, "write_size_kb": full_w,
                     "bytes_per_launch": 2.0 * full_f * 1024.0 + full_w * 1024.0,
                     "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x 2 (gfx950), largest launch of the run; " + frames_line})
