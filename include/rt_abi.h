@@ -100,8 +100,9 @@ enum {
      * rendered by one kernel launch, every pixel keeping its accumulation value in registers from
      * one frame to the next - the additions a sequence of single-frame dispatches performs, in the
      * same order, so both images are the same bit for bit; the draw image is written for the last
-     * frame of a launch only. Saves the launch ramps and draw-image writes. Default 8; 1 = one launch per
-     * frame. rt_render_frame (one frame) is not affected. */
+     * frame of a launch only. Saves the launch ramps and draw-image writes. Default 32 (fewer where the
+     * pieces of RT_OPT_LAUNCH_PIECES would take more than 4 GiB); 1 = one launch per frame. rt_render_frame
+     * (one frame) is not affected. */
     RT_OPT_FRAMES_PER_LAUNCH = 16,
     /* Traversal of the BVH parents by the lock-step kernels (pipelines 0 and 3) in path-tracing mode.
      * 0 (default) = the reference's trees in the reference's order (left child first,
@@ -127,6 +128,15 @@ enum {
      * not); 2 = four-child records without that hierarchy; 0 = two-child records. Other pipelines and
      * mixed scenes always walk two-child records. */
     RT_OPT_WIDE_RECORDS = 20,
+    /* Pipeline 3, rt_render_frames launches of more than two frames: 1 = a launch is rendered in pieces of two
+     * frames - four times as many, shorter waves, each storing its frames' contributions, which a second small
+     * kernel adds to the accumulation image in frame order (the same additions in the same order: same images) -
+     * so that a launch that holds little more than the waves the chip runs at one time (a rank's share of a tile
+     * split, a small image) does not last as long as all the frames of its most expensive tile, and faster on
+     * every scene measured (the default scene 1.5 %, the 1M-triangle scene 12 %); the default. 0 = one piece;
+     * 2 = in pieces only when the launch holds fewer than three times the resident waves. Needs 16 bytes of
+     * device memory per pixel and frame of a launch. */
+    RT_OPT_LAUNCH_PIECES = 21,
     /* Read-only (rt_get_option) facts about the uploaded scene: traversal stack entries a lane can
      * need (longest chain of two-child records), number of two-child records, and number of
      * triangle records in leaf order (a triangle that several leaves share counts once per leaf). */

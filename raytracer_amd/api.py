@@ -21,6 +21,7 @@ RT_OPT_WF_ROUNDS, RT_OPT_WF_REFILL, RT_OPT_WF_WALK_WAVES, RT_OPT_WF_PARTS = 12, 
 RT_OPT_FRAMES_PER_LAUNCH = 16
 RT_OPT_TRAVERSAL, RT_OPT_SAH_MAX_LEAF, RT_OPT_TEAM_WALKERS = 17, 18, 19
 RT_OPT_WIDE_RECORDS = 20
+RT_OPT_LAUNCH_PIECES = 21
 RT_INFO_WIDE_RECORDS, RT_INFO_WIDE_STACK_NEED, RT_INFO_TLAS_RECORDS = 107, 108, 109
 RT_INFO_STACK_DEPTH, RT_INFO_RECORDS, RT_INFO_TRIANGLES = 100, 101, 102
 RT_INFO_FAST_OBJECTS, RT_INFO_FAST_RECORDS, RT_INFO_FAST_TRIANGLES, RT_INFO_FAST_STACK_DEPTH = 103, 104, 105, 106

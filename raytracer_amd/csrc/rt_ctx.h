@@ -86,7 +86,10 @@ struct rt_ctx {
     hipEvent_t wfFork = nullptr, wfJoin[kMaxParts] = {};
     size_t wfKey[6] = {};
     int wfRounds = 5, wfRefill = 16, wfWalkWaves = 12, wfParts = 1;
-    int framesPerLaunch = 8;
+    int framesPerLaunch = 32;
+    int optPieces = 1;            // RT_OPT_LAUNCH_PIECES
+    void* dPartial = nullptr;     // per-frame contributions of a launch in pieces: frames x width x height float4
+    size_t partialBytes = 0;
 
     int optFast = 0, optPipeline = 3, tileRank = 0, tileWorld = 1, tileSize = 64;
     // multi-GPU merge (rt_comm.hip): RCCL communicator of this context and the tile-exchange buffer

@@ -166,6 +166,13 @@ struct DevLaunch {
     /* lock-step kernel, path tracing: consecutive frames rendered by one launch (>= 1) and the step
      * of the frame index between them */
     int32_t frames, frameStride;
+    /* Two-samples-per-lane kernel, launches in pieces (partial != null): the launch's frames are cut into pieces of
+     * pieceFrames frames, block b renders piece b % pieces of the 8x8 pixels of wave b / pieces and stores each
+     * frame's contribution (the value a dispatch adds to the accumulation pixel) at partial[frame in launch][pixel];
+     * rt_sum_pieces then adds them to the accumulation image in frame order - the additions a launch in one piece
+     * performs, in the same order - and writes the draw image. More and shorter waves: a launch lasts as long as its
+     * slowest wave, which matters when a launch holds little more than the waves the chip runs at one time. */
+    int32_t pieces, pieceFrames;
 };
 
 /* Buffers of the wavefront pipeline. A ray that leaves the path kernel becomes a job: a record

@@ -39,8 +39,8 @@ hipError_t rt_launch_megakernel_strict(const DevScene*, const rt_push_constants*
                                        DevCounters*, int, int, hipStream_t);
 hipError_t rt_launch_megakernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
                                      DevCounters*, int, int, hipStream_t);
-hipError_t rt_launch_pairkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, int, hipStream_t);
-hipError_t rt_launch_pairkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, int, hipStream_t);
+hipError_t rt_launch_pairkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, int, void*, hipStream_t);
+hipError_t rt_launch_pairkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, int, void*, hipStream_t);
 hipError_t rt_launch_schedkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
                                         DevCounters*, int, int, unsigned long long*, int, hipStream_t, unsigned long long*);
 hipError_t rt_launch_schedkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
@@ -139,6 +139,9 @@ void freeImages(rt_ctx* c)
     if (c->ownDraw) (void)hipFree(c->ownDraw);
     if (c->ownAccum) (void)hipFree(c->ownAccum);
     c->ownDraw = c->ownAccum = nullptr;
+    if (c->dPartial) (void)hipFree(c->dPartial);
+    c->dPartial = nullptr;
+    c->partialBytes = 0;
 }
 
 struct Float4 { float x, y, z, w; };
@@ -808,7 +811,25 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
                ((long long)frames * pc.raysPerPixel >= 2 || (L.tileSize & 15) == 0)) {
         // two samples of a pixel per lane; a launch that holds one sample per pixel pairs two pixels instead
         auto fn = ctx->optFast ? rt_launch_pairkernel_fast : rt_launch_pairkernel_strict;
-        e = fn(scene, &pc, &L, ctx->accum, ctx->draw, (long long)frames * pc.raysPerPixel < 2 ? 1 : 0, ctx->stream);
+        // launches in pieces (RT_OPT_LAUNCH_PIECES): pieces of two frames, their contributions summed in frame order afterwards
+        void* partial = nullptr;
+        const long long waves = (long long)L.ownedTiles * (L.tileSize / 8) * (L.tileSize / 8);
+        const long long resident = (long long)std::max(1, ctx->computeUnits) * 16;
+        const bool inPieces = frames > 2 && (ctx->optPieces == 1 || (ctx->optPieces == 2 && waves < 3 * resident));
+        if (inPieces) {
+            const size_t need = (size_t)frames * (size_t)ctx->width * (size_t)ctx->height * 16;
+            if (need > ctx->partialBytes) {
+                RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->dPartial) (void)hipFree(ctx->dPartial);
+                ctx->dPartial = nullptr; ctx->partialBytes = 0;
+                RT_HIP(ctx, hipMalloc(&ctx->dPartial, need));
+                ctx->partialBytes = need;
+            }
+            partial = ctx->dPartial;
+            L.pieceFrames = 2;
+            L.pieces = (frames + 1) / 2;
+        }
+        e = fn(scene, &pc, &L, ctx->accum, ctx->draw, (long long)frames * pc.raysPerPixel < 2 ? 1 : 0, partial, ctx->stream);
     } else {
         // the depth / box views and the degenerate raysPerPixel <= 0 case stay on the lock-step kernel
         auto fn = ctx->optFast ? rt_launch_megakernel_fast : rt_launch_megakernel_strict;
@@ -919,6 +940,10 @@ int rt_set_option(rt_ctx* ctx, int option, int value) try
         if (value < 1 || value > 4096) return rt_fail(ctx, RT_ERR_INVALID_ARG, "frames per launch must be in [1,4096]");
         ctx->framesPerLaunch = value;
         return RT_OK;
+    case RT_OPT_LAUNCH_PIECES:
+        if (value < 0 || value > 2) return rt_fail(ctx, RT_ERR_INVALID_ARG, "launch pieces must be 0 (never), 1 (always) or 2 (when a launch holds few waves)");
+        ctx->optPieces = value;
+        return RT_OK;
     case RT_OPT_TEAM_WALKERS:
         if (value < 1 || value > 8) return rt_fail(ctx, RT_ERR_INVALID_ARG, "walker waves per workgroup must be in [1,8]");
         ctx->teamWalkers = value;
@@ -981,6 +1006,7 @@ int rt_get_option(rt_ctx* ctx, int option, int* value) try
     case RT_OPT_WF_PARTS: *value = ctx->wfParts; return RT_OK;
     case RT_OPT_FRAMES_PER_LAUNCH: *value = ctx->framesPerLaunch; return RT_OK;
     case RT_OPT_TEAM_WALKERS: *value = ctx->teamWalkers; return RT_OK;
+    case RT_OPT_LAUNCH_PIECES: *value = ctx->optPieces; return RT_OK;
     case RT_OPT_TRAVERSAL: *value = ctx->optTraversal; return RT_OK;
     case RT_OPT_SAH_MAX_LEAF: *value = ctx->sahMaxLeaf; return RT_OK;
     case RT_OPT_WIDE_RECORDS: *value = !ctx->optWide ? 0 : ctx->optTlas ? 1 : 2; return RT_OK;
@@ -1167,7 +1193,12 @@ int rt_render_frames(rt_ctx* ctx, const rt_push_constants* pc, int first_frame, 
     // the lock-step kernel can run several consecutive frames of a pixel in one launch (same
     // arithmetic in the same order, one read and one write of the accumulation pixel)
     const bool fuse = (ctx->optPipeline == 0 || ctx->optPipeline == 3 || ctx->optPipeline == 4) && pc->renderMode == 0 && pc->raysPerPixel >= 1 && ctx->framesPerLaunch > 1;
-    const int group = fuse ? ctx->framesPerLaunch : 1;
+    int group = fuse ? ctx->framesPerLaunch : 1;
+    // launches in pieces keep 16 bytes per pixel and frame: at most 4 GiB of it
+    if (fuse && ctx->optPipeline == 3 && ctx->optPieces != 0) {
+        const size_t perFrame = (size_t)ctx->width * (size_t)ctx->height * 16;
+        group = (int)std::max<size_t>(2, std::min<size_t>((size_t)group, ((size_t)4 << 30) / std::max<size_t>(perFrame, 1)));
+    }
     for (int k = 0; k < count; k += group) {
         const int n = std::min(group, count - k);
         p.frame = first_frame + k * stride;

@@ -1683,7 +1683,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_MEGA_WAVE
 #endif
 template <int NF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVES))) void RT_SYM(rt_pairkernel)(DevScene S, rt_push_constants pc, DevLaunch L,
-                                                            float4* __restrict__ accum, float4* __restrict__ out)
+                                                            float4* __restrict__ accum, float4* __restrict__ out, float4* __restrict__ partial)
 {
     extern __shared__ uint2 stackMem[];
     const int lane = threadIdx.x;
@@ -1698,8 +1698,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
 
     const int wavesX = L.tileSize >> 3;
     const int wavesPerTile = wavesX * wavesX;
-    const int ownedTile = blockIdx.x / wavesPerTile;
-    const int sub = blockIdx.x - ownedTile * wavesPerTile;
+    // a launch in pieces: this block renders piece `piece` of the launch's frames for its 8x8 pixels
+    const int piece = partial ? (int)blockIdx.x % L.pieces : 0;
+    const int wave = partial ? (int)blockIdx.x / L.pieces : (int)blockIdx.x;
+    const int ownedTile = wave / wavesPerTile;
+    const int sub = wave - ownedTile * wavesPerTile;
     const int tile = L.tileRank + ownedTile * L.tileWorld;
     int tx, ty;
     rt_tile_of_position(tile, L.tilesX, &tx, &ty);
@@ -1710,7 +1713,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
     const size_t idx = (size_t)y * (size_t)L.width + (size_t)x;
 
     const int rpp = pc.raysPerPixel;
-    const int total = L.frames * rpp;                 // samples of this pixel in this launch
+    const int framesHere = partial ? min(L.pieceFrames, L.frames - piece * L.pieceFrames) : L.frames;
+    const int total = framesHere * rpp;               // samples of this pixel in this launch (in this piece of it)
+    const int mBase = piece * L.pieceFrames * rpp;    // entry of the launch's sample sequence this block starts at
+    const size_t pixels = (size_t)L.width * (size_t)L.height;
     const int bounces = pc.maxBounces + 1;
     const float raysPerPixelRatio = 1.0f / (float)rpp;
     const V3 sunDirN = normalize3(-ld3(pc.sunDirection));
@@ -1731,7 +1737,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             p.result = mk(0.0f, 0.0f, 0.0f);
             p.sun = mk(0.0f, 0.0f, 0.0f);
             p.so = mk(0.0f, 0.0f, 0.0f);
-            const uint32_t seed = pair_seed(pc, L, x, y, m, rpp);
+            const uint32_t seed = pair_seed(pc, L, x, y, mBase + m, rpp);
             Ray ray = get_ray(pc, x, y, seed);
             p.o = ray.o; p.d = normalize3(ray.d);
             p.draws = scatter_draws(seed);
@@ -1749,8 +1755,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             trace_pair<false, NF>(S, pc.parentBVHCount, P[0].o, dirA, P[0].alive, bA, P[1].o, dirB, P[1].alive, bB, 0.001f, 1e20f, stack);
             // (the seed of a sample is recomputed where it is needed rather than carried through the walks)
             RT_SEC_BEGIN(secShade);
-            pair_shade<RES>(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, y, n, rpp), res);
-            pair_shade<RES>(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, y, n + 1, rpp), res + RES_PER_PATH * 64);
+            pair_shade<RES>(S, pc, P[0], dirA, bA, pair_seed(pc, L, x, y, mBase + n, rpp), res);
+            pair_shade<RES>(S, pc, P[1], dirB, bB, pair_seed(pc, L, x, y, mBase + n + 1, rpp), res + RES_PER_PATH * 64);
             RT_SEC_END(4, secShade);
             if (P[0].shadow || P[1].shadow) {
                 trace_pair<true, NF>(S, pc.parentBVHCount, P[0].so, sunDirN, P[0].shadow, bA, P[1].so, sunDirN, P[1].shadow, bB, 0.001f, 1e20f, stack);
@@ -1771,15 +1777,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
             const int fr = m / rpp, i = m - fr * rpp;
             if (i == rpp - 1) {
                 // end of a frame: the pixel goes through memory as in the one-sample kernel
-                float4 acc = accum[idx];
                 nc = nc * raysPerPixelRatio;
-                acc.x += nc.x; acc.y += nc.y; acc.z += nc.z;
-                accum[idx] = acc;
+                if (partial) {
+                    partial[(size_t)(piece * L.pieceFrames + fr) * pixels + idx] = make_float4(nc.x, nc.y, nc.z, 0.0f);
+                } else {
+                    float4 acc = accum[idx];
+                    acc.x += nc.x; acc.y += nc.y; acc.z += nc.z;
+                    accum[idx] = acc;
+                }
                 if (m + 1 < total) nc = mk(0.0f, 0.0f, 0.0f);
             }
         }
         if (NC_LDS) res_st(res, RES_RESULT, nc);
     }
+    if (partial) { RT_WORK_END(); return; }      // rt_sum_pieces adds the pieces up and writes the draw image
     if (NC_LDS) nc = res_ld(res, RES_RESULT);
     const int lastFrame = pc.frame + (L.frames - 1) * L.frameStride;
     const float accumulationMultiplier = pc.accumulateFrames == 1 ? 1.0f / (float)(lastFrame + 1) : 1.0f;
@@ -3005,6 +3016,40 @@ __global__ __launch_bounds__(64) void RT_SYM(rt_wf_walk)(DevScene S, rt_push_con
 #include "rt_team.inl"
 
 // draw = gamma(accum.rgb * 1/total_frames), draw.a = accum.a (raytrace.comp:794-801)
+// Second half of a launch in pieces (DevLaunch::pieces): the frames' contributions are added to the accumulation pixel in
+// frame order, one after the other as separate dispatches would add them, and the draw pixel is written for the last
+// frame (Pathtrace, raytrace.comp:787-803). Same block -> pixel map as the kernels that wrote the pieces.
+__global__ __launch_bounds__(64) void RT_SYM(rt_sum_pieces)(rt_push_constants pc, DevLaunch L, float4* __restrict__ accum, float4* __restrict__ out,
+                                                            const float4* __restrict__ partial)
+{
+    const int lane = threadIdx.x;
+    const int wavesX = L.tileSize >> 3;
+    const int wavesPerTile = wavesX * wavesX;
+    const int ownedTile = blockIdx.x / wavesPerTile;
+    const int sub = blockIdx.x - ownedTile * wavesPerTile;
+    const int tile = L.tileRank + ownedTile * L.tileWorld;
+    int tx, ty;
+    rt_tile_of_position(tile, L.tilesX, &tx, &ty);
+    const int sy = sub / wavesX, sx = sub - sy * wavesX;
+    const int x = tx * L.tileSize + sx * 8 + (lane & 7);
+    const int y = ty * L.tileSize + sy * 8 + (lane >> 3);
+    if (!(x < L.width && y < L.height)) return;
+    const size_t idx = (size_t)y * (size_t)L.width + (size_t)x;
+    const size_t pixels = (size_t)L.width * (size_t)L.height;
+    float4 acc = accum[idx];
+    float4 nc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int f = 0; f < L.frames; ++f) {
+        nc = partial[(size_t)f * pixels + idx];
+        acc.x += nc.x; acc.y += nc.y; acc.z += nc.z;
+    }
+    accum[idx] = acc;
+    const int lastFrame = pc.frame + (L.frames - 1) * L.frameStride;
+    const float accumulationMultiplier = pc.accumulateFrames == 1 ? 1.0f / (float)(lastFrame + 1) : 1.0f;
+    float4 avg = pc.accumulateFrames == 1 ? acc : make_float4(nc.x, nc.y, nc.z, 1.0f);
+    avg.x *= accumulationMultiplier; avg.y *= accumulationMultiplier; avg.z *= accumulationMultiplier;
+    out[idx] = make_float4(linear_to_gamma(avg.x), linear_to_gamma(avg.y), linear_to_gamma(avg.z), avg.w);
+}
+
 __global__ __launch_bounds__(256) void RT_SYM(rt_resolve_kernel)(const float4* __restrict__ accum, float4* __restrict__ out,
                                                                  size_t pixels, float multiplier)
 {
@@ -3072,11 +3117,13 @@ extern "C" hipError_t RT_SYM(rt_launch_megakernel)(const DevScene* S, const rt_p
 }
 
 extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_push_constants* pc, const DevLaunch* L,
-                                                   void* accum, void* out, int pixelPairs, hipStream_t stream)
+                                                   void* accum, void* out, int pixelPairs, void* partial, hipStream_t stream)
 {
     const int wavesX = L->tileSize / 8;
     if (pixelPairs && (L->tileSize & 15)) return hipErrorInvalidValue;      // 8 x 16 pixel footprints need whole 16-row bands
-    const long long blocks = (long long)L->ownedTiles * wavesX * (pixelPairs ? wavesX / 2 : wavesX);
+    const long long waves = (long long)L->ownedTiles * wavesX * (pixelPairs ? wavesX / 2 : wavesX);
+    if (partial && (pixelPairs || L->pieces < 1 || L->pieceFrames < 1 || (long long)L->pieces * L->pieceFrames < L->frames)) return hipErrorInvalidValue;
+    const long long blocks = partial ? waves * L->pieces : waves;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // wide scenes: the walk keeps RT_WIDE_LDS_LEVELS entries of a lane's stack in LDS (deeper ones in private memory), the LDS-resident path state behind them
@@ -3090,13 +3137,17 @@ extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_p
     // <3> walks them from the hierarchy over the parents' boxes (wide scenes with many BVH parents)
     const bool nf = S->nearFirstBase != 0x7fffffff, wide = S->nodes4 != nullptr, tlas = wide && S->tlasRoot != RT_REF_EMPTY;
     if (tlas && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<3>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else if (tlas) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<3>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (tlas) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<3>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out, (float4*)partial);
     else if (wide && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<2>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else if (wide) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<2>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (wide) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<2>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out, (float4*)partial);
     else if (nf && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<1>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else if (nf) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<1>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (nf) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<1>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out, (float4*)partial);
     else if (pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<0>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
-    else hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<0>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<0>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out, (float4*)partial);
+    if (partial) {
+        if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+        hipLaunchKernelGGL(RT_SYM(rt_sum_pieces), dim3((unsigned)waves), block, 0, stream, *pc, *L, (float4*)accum, (float4*)out, (const float4*)partial);
+    }
     return hipGetLastError();
 }
 

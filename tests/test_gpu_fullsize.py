@@ -70,15 +70,15 @@ def generated(tmp_path_factory):
 
 
 def test_default_scene_2560x1369_multi_frame_launch(R, default_scene_arrays):
-    """The headline benchmark configuration as the benchmark runs it: ONE rt_render_frames call of 8 frames on the default
-    pipeline (two samples per lane, 8 frames per launch) at 2560x1369, against 8 single-frame dispatches
+    """The headline benchmark configuration: ONE rt_render_frames call of 8 frames on the default pipeline (two samples
+    per lane, the launch rendered in pieces of two frames) at 2560x1369, against 8 single-frame dispatches
     of the lock-step kernel and against oracle windows."""
     W, H = 2560, 1369
     frames = list(range(8))
     r = R.Renderer(0)
     try:
         r.upload_scene(default_scene_arrays); r.resize(W, H)
-        assert r.get_option(R.RT_OPT_PIPELINE) == 3 and r.get_option(R.RT_OPT_FRAMES_PER_LAUNCH) == 8
+        assert r.get_option(R.RT_OPT_PIPELINE) == 3 and r.get_option(R.RT_OPT_FRAMES_PER_LAUNCH) == 32 and r.get_option(R.RT_OPT_LAUNCH_PIECES) == 1
         opc = scenes.make_pc(default_scene_arrays, W, H)
         r.render_frames(to_pc(R, opc), 0, 1, 8)
         acc = r.read_image(R.RT_IMAGE_ACCUM); out = r.read_image(R.RT_IMAGE_DRAW)
@@ -108,6 +108,44 @@ def test_default_scene_2560x1369_multi_frame_launch(R, default_scene_arrays):
         same = np.all(bits(nacc[..., :3]) == bits(acc[..., :3]), axis=-1)
         within = np.all(np.abs(nacc[..., :3] - acc[..., :3]) <= 1e-4 + 1e-4 * np.abs(acc[..., :3]), axis=-1)
         assert same.mean() >= 0.9999 and (same | within).mean() >= 0.995, (same.mean(), within.mean())
+        mse = np.mean((np.clip(nout[..., :3], 0, 1).astype(np.float64) - np.clip(out[..., :3], 0, 1)) ** 2)
+        assert mse == 0 or 10 * np.log10(1.0 / mse) >= 45.0
+    finally:
+        r.close()
+
+
+def test_default_scene_2560x1369_benchmark_step(R, default_scene_arrays):
+    """One step of the benchmark as bench.py runs it: 64 frames in ONE rt_render_frames call at 2560x1369 (two launches
+    of 32 frames, each in pieces of two frames, the accumulation image carried from launch to launch). Reference
+    order: bit-exact against oracle windows that accumulate all 64 frames; the same call as launches of 8 frames in
+    one piece gives the same image; near-first: within the bars of the reference-order image."""
+    W, H = 2560, 1369
+    frames = list(range(64))
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays); r.resize(W, H)
+        opc = scenes.make_pc(default_scene_arrays, W, H)
+        r.render_frames(to_pc(R, opc), 0, 1, 64)
+        acc = r.read_image(R.RT_IMAGE_ACCUM); out = r.read_image(R.RT_IMAGE_DRAW)
+        windows = [(1248, 568, 1312, 600),      # the dragon
+                   (900, 608, 964, 640),        # wall and floor edges
+                   (2496, 1337, 2560, 1369)]    # bottom right corner, ragged last row of waves
+        check_windows(default_scene_arrays, opc, frames, W, H, windows, acc, out, "64 frames at 2560x1369")
+        r.set_option(R.RT_OPT_LAUNCH_PIECES, 0)
+        r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, 8)
+        r.clear_accumulation()
+        opc["frame"] = 0
+        r.render_frames(to_pc(R, opc), 0, 1, 64)
+        assert np.array_equal(bits(r.read_image(R.RT_IMAGE_ACCUM)), bits(acc)) and np.array_equal(bits(r.read_image(R.RT_IMAGE_DRAW)), bits(out))
+        r.set_option(R.RT_OPT_LAUNCH_PIECES, 1)
+        r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, 32)
+        r.set_option(R.RT_OPT_TRAVERSAL, 1)
+        r.clear_accumulation()
+        r.render_frames(to_pc(R, opc), 0, 1, 64)
+        nacc = r.read_image(R.RT_IMAGE_ACCUM); nout = r.read_image(R.RT_IMAGE_DRAW)
+        same = np.all(bits(nacc[..., :3]) == bits(acc[..., :3]), axis=-1)
+        within = np.all(np.abs(nacc[..., :3] - acc[..., :3]) <= 1e-4 + 1e-4 * np.abs(acc[..., :3]), axis=-1)
+        assert same.mean() >= 0.999 and (same | within).mean() >= 0.995, (same.mean(), within.mean())
         mse = np.mean((np.clip(nout[..., :3], 0, 1).astype(np.float64) - np.clip(out[..., :3], 0, 1)) ** 2)
         assert mse == 0 or 10 * np.log10(1.0 / mse) >= 45.0
     finally:
@@ -182,8 +220,8 @@ def test_generated_configs_full_size(R, generated, name):
 
 def test_default_scene_3840x2160_one_launch(R, default_scene_arrays):
     """Benchmark configuration 3's image size: one launch of 8 frames at 3840x2160, twice (same bits), against
-    the in-order accumulation of single frames, against an oracle window, and as rank 1 of a 2-way
-    sample split (frames 1, 3, 5, ...)."""
+    the in-order accumulation of single frames, against an oracle window, the near-first flavour of the same launch
+    against it over the whole image, and as rank 1 of a 2-way sample split (frames 1, 3, 5, ...)."""
     W, H = 3840, 2160
     r = R.Renderer(0)
     try:
@@ -207,6 +245,18 @@ def test_default_scene_3840x2160_one_launch(R, default_scene_arrays):
         assert np.array_equal(bits(out[..., :3]), bits(want))
         check_windows(default_scene_arrays, opc, list(range(8)), W, H, [(1850, 850, 1978, 898), (3776, 2128, 3840, 2160)], acc, out, "4K")
         r.set_option(R.RT_OPT_PIPELINE, 3)
+        # the near-first flavour for the same launch at this size, whole image against the reference-order image
+        r.set_option(R.RT_OPT_TRAVERSAL, 1)
+        r.clear_accumulation()
+        opc["frame"] = 0
+        r.render_frames(to_pc(R, opc), 0, 1, 8)
+        nacc = r.read_image(R.RT_IMAGE_ACCUM); nout = r.read_image(R.RT_IMAGE_DRAW)
+        same = np.all(bits(nacc[..., :3]) == bits(acc[..., :3]), axis=-1)
+        within = np.all(np.abs(nacc[..., :3] - acc[..., :3]) <= 1e-4 + 1e-4 * np.abs(acc[..., :3]), axis=-1)
+        assert same.mean() >= 0.9999 and (same | within).mean() >= 0.995, (same.mean(), within.mean())
+        mse = np.mean((np.clip(nout[..., :3], 0, 1).astype(np.float64) - np.clip(out[..., :3], 0, 1)) ** 2)
+        assert mse == 0 or 10 * np.log10(1.0 / mse) >= 45.0
+        r.set_option(R.RT_OPT_TRAVERSAL, 0)
         r.clear_accumulation()
         r.render_frames(to_pc(R, opc), 1, 2, 4)
         acc = r.read_image(R.RT_IMAGE_ACCUM)

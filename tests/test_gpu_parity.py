@@ -325,7 +325,36 @@ def test_tile_partition_is_bit_identical(R, rdr, default_scene_arrays):
     W, H = 200, 120
     rdr.set_option(R.RT_OPT_FAST_MATH, 0)
     opc = scenes.make_pc(default_scene_arrays, W, H)
-    full_acc, full_out = gpu_frames(R, rdr, opc, [0, 1], W, H)
+    _tile_partition(R, rdr, default_scene_arrays, opc, W, H, [0, 1])
+
+
+@pytest.mark.parametrize("traversal", [0, 1], ids=["reference-order", "near-first"])
+def test_tile_partition_launches_in_pieces(R, default_scene_arrays, traversal):
+    """The same with launches of seven frames rendered in pieces of two frames (the launch shape of a tile split's
+    ranks: RT_OPT_LAUNCH_PIECES 1): every rank's tiles equal the single-GPU image, which equals the oracle's in
+    reference order, and the image of launches in one piece in both orders."""
+    W, H = 200, 120
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays)
+        r.set_option(R.RT_OPT_PIPELINE, 3)
+        r.set_option(R.RT_OPT_TRAVERSAL, traversal)
+        opc = scenes.make_pc(default_scene_arrays, W, H)
+        frames = list(range(7))
+        r.set_option(R.RT_OPT_LAUNCH_PIECES, 0)
+        one_acc, one_out = gpu_frames(R, r, opc, frames, W, H)
+        r.set_option(R.RT_OPT_LAUNCH_PIECES, 1)
+        full_acc, full_out = _tile_partition(R, r, default_scene_arrays, opc, W, H, frames)
+        assert np.array_equal(bits(full_acc), bits(one_acc)) and np.array_equal(bits(full_out), bits(one_out))
+        if traversal == 0:
+            want = oracle_frames(default_scene_arrays, opc, frames, W, H)
+            assert np.array_equal(bits(full_acc), bits(want["accum"])) and np.array_equal(bits(full_out), bits(want["out"]))
+    finally:
+        r.close()
+
+
+def _tile_partition(R, rdr, default_scene_arrays, opc, W, H, frames):
+    full_acc, full_out = gpu_frames(R, rdr, opc, frames, W, H)
     world = 3
     rdr.set_option(R.RT_OPT_TILE_SIZE, 32)
     rdr.set_option(R.RT_OPT_TILE_WORLD, world)
@@ -335,7 +364,7 @@ def test_tile_partition_is_bit_identical(R, rdr, default_scene_arrays):
         for rank in range(world):
             rdr.set_option(R.RT_OPT_TILE_RANK, rank)
             rdr.resize(W, H)                       # fresh, zeroed draw + accumulation images
-            acc, out = gpu_frames(R, rdr, opc, [0, 1], W, H)
+            acc, out = gpu_frames(R, rdr, opc, frames, W, H)
             touched = np.any(bits(acc) != 0, axis=2) | np.any(bits(out) != 0, axis=2)
             owner += touched
             sum_acc += acc
@@ -349,6 +378,7 @@ def test_tile_partition_is_bit_identical(R, rdr, default_scene_arrays):
         rdr.set_option(R.RT_OPT_TILE_RANK, 0)
         rdr.set_option(R.RT_OPT_TILE_WORLD, 1)
         rdr.set_option(R.RT_OPT_TILE_SIZE, 64)
+    return full_acc, full_out
 
 
 def test_sample_split_merge_and_resolve(R, rdr, default_scene_arrays):
@@ -550,13 +580,17 @@ def test_frames_per_launch_does_not_change_results(R, default_scene_arrays):
                     one = (r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW))
                     if fast == 0:   # (the fast flavour is only the same from launch shape to launch shape of one kernel)
                         assert np.array_equal(bits(one[0]), bits(want["accum"])) and np.array_equal(bits(one[1]), bits(want["out"]))
-                    for group in (2, 3, 7, 8, 64):
+                    # pipeline 3 renders a launch of more than two frames in pieces of two frames, summed in frame order
+                    # afterwards (RT_OPT_LAUNCH_PIECES 1, the default), or in one piece (0)
+                    for group, pieces in ((2, 1), (3, 1), (7, 1), (8, 1), (64, 1), (3, 0), (7, 0), (64, 0), (5, 2)):
                         r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, group)
+                        r.set_option(R.RT_OPT_LAUNCH_PIECES, pieces)
                         r.clear_accumulation()
                         r.render_frames(to_pc(R, opc), 2, 3, 7)
                         got = (r.read_image(R.RT_IMAGE_ACCUM), r.read_image(R.RT_IMAGE_DRAW))
-                        assert np.array_equal(bits(got[0]), bits(one[0])), (accumulate, fast, pipeline, group)
-                        assert np.array_equal(bits(got[1]), bits(one[1])), (accumulate, fast, pipeline, group)
+                        assert np.array_equal(bits(got[0]), bits(one[0])), (accumulate, fast, pipeline, group, pieces)
+                        assert np.array_equal(bits(got[1]), bits(one[1])), (accumulate, fast, pipeline, group, pieces)
+                    r.set_option(R.RT_OPT_LAUNCH_PIECES, 1)
                 r.set_option(R.RT_OPT_PIPELINE, 0)
         with pytest.raises(R.RtError):
             r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, 0)
