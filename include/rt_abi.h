@@ -90,11 +90,12 @@ enum {
     /* Pipeline 2: number of suspend / walk / resume rounds before the remaining paths are
      * finished with in-place walks (default 5; 0 = in-place walks only), and the number of
      * free lanes at which a walking wave fetches new rays (default 16), and the number of resident
-     * waves per compute unit of the walk kernel (default 12). WF_PARTS (default 1, at most 8): the
+     * waves per compute unit of the walk kernel (default 12). WF_PARTS (default 1, at most 3): the
      * tiles are dealt out to that many partitions, each rendered by its own chain of kernels on
-     * its own stream, so that the thin end of one chain overlaps with the bulk of another (3 is
-     * the fastest setting measured; more streams than hardware queues serialise, and two processes
-     * that share one GPU should stay at 1). */
+     * its own stream, so that the thin end of one chain overlaps with the bulk of another. Every
+     * chain needs a hardware queue of its own beside the context's (a process has four): more are
+     * refused, because chains that share a queue serialise behind each other's fork / join events;
+     * two processes that share one GPU should stay at 1. */
     RT_OPT_WF_ROUNDS = 12, RT_OPT_WF_REFILL = 13, RT_OPT_WF_WALK_WAVES = 14, RT_OPT_WF_PARTS = 15,
     /* Pipeline 0, rt_render_frames in path-tracing mode: this many consecutive frames of the call are
      * rendered by one kernel launch, every pixel keeping its accumulation value in registers from

@@ -41,6 +41,17 @@ typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, void*, hipStrea
 typedef int (*AllGatherFn)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef const char* (*GetErrorStringFn)(int);
 const int kRcclFloat = 7, kRcclChar = 0, kRcclSum = 0;
+// Where the RCCL header is installed, the values and the size of the id are checked against it at compile time (the
+// library is still only opened at run time, with dlopen: a single-GPU user never loads it).
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+} // namespace
+#include <rccl/rccl.h>
+namespace {
+static_assert(ncclFloat == kRcclFloat && ncclChar == kRcclChar && ncclSum == kRcclSum, "RCCL enum values differ from the ones this file passes");
+static_assert(sizeof(ncclUniqueId) == sizeof(RcclId) && NCCL_UNIQUE_ID_BYTES == RT_COMM_ID_BYTES, "RCCL unique id size differs");
+#endif
+#endif
 
 struct Rccl {
     void* handle = nullptr;

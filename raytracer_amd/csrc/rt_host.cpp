@@ -53,6 +53,7 @@ hipError_t rt_launch_wf_walk_strict(const DevScene*, const rt_push_constants*, c
 hipError_t rt_launch_wf_walk_fast(const DevScene*, const rt_push_constants*, const DevWavefront*, int, int, int, hipStream_t);
 hipError_t rt_launch_teamkernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, unsigned long long*, int, int, int, hipStream_t);
 hipError_t rt_launch_teamkernel_fast(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*, unsigned long long*, int, int, int, hipStream_t);
+size_t rt_team_lds_bytes(int stackDepth, int walkers);
 hipError_t rt_launch_math_strict(int, const float*, float*, size_t, hipStream_t);
 hipError_t rt_launch_math_fast(int, const float*, float*, size_t, hipStream_t);
 hipError_t rt_launch_resolve_strict(const void*, void*, size_t, float, hipStream_t);
@@ -803,7 +804,10 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
         auto fn = ctx->optFast ? rt_launch_schedkernel_fast : rt_launch_schedkernel_strict;
         e = fn(&ctx->scene, &pc, &L, ctx->accum, ctx->draw, statsOnly ? ctx->dCounters : nullptr, countBuild ? 1 : 0,
                statsOnly ? 1 : 0, ctx->dQueue, blocks, ctx->stream, diag);
-    } else if (ctx->optPipeline == 4 && pc.renderMode == 0 && !statsOnly && pc.raysPerPixel >= 1) {
+    } else if (ctx->optPipeline == 4 && pc.renderMode == 0 && !statsOnly && pc.raysPerPixel >= 1 &&
+               rt_team_lds_bytes(scene->stackDepth, ctx->teamWalkers) <= (size_t)160 * 1024) {
+        // (a tree so deep that the walkers' stacks do not fit the workgroup's LDS beside the job slots is rendered
+        // by the lock-step kernels below: same images)
         // one workgroup of 16 waves per compute unit; its path waves pull tiles from a counter
         auto fn = ctx->optFast ? rt_launch_teamkernel_fast : rt_launch_teamkernel_strict;
         e = fn(scene, &pc, &L, ctx->accum, ctx->draw, ctx->dQueue, std::max(1, ctx->computeUnits), ctx->teamWalkers, ctx->wfRefill, ctx->stream);
@@ -933,7 +937,9 @@ int rt_set_option(rt_ctx* ctx, int option, int value) try
         ctx->wfWalkWaves = value;
         return RT_OK;
     case RT_OPT_WF_PARTS:
-        if (value < 1 || value > rt_ctx::kMaxParts) return rt_fail(ctx, RT_ERR_INVALID_ARG, "wavefront partitions must be in [1,8]");
+        // a partition's chain of kernels runs on a stream of its own: with the context's stream that is one hardware queue each,
+        // and a process has four (GPU_MAX_HW_QUEUES); chains that share a queue wait for one another behind fork / join events
+        if (value < 1 || value > 3) return rt_fail(ctx, RT_ERR_INVALID_ARG, "wavefront partitions must be in [1,3] (one hardware queue each beside the context's own; a process has four)");
         ctx->wfParts = value;
         return RT_OK;
     case RT_OPT_FRAMES_PER_LAUNCH:
@@ -1293,6 +1299,14 @@ int rt_frame_stats_noalloc(rt_ctx* ctx, const rt_push_constants* pc, rt_frame_st
         if (e != hipSuccess) (void)hipGetLastError();
         if (e != hipSuccess || !(at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged))
             return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_frame_stats_noalloc: out_dev must be device memory or pinned host memory");
+        // memory of another GPU is only reachable with peer access, which this entry point does not set up
+        if (at.type == hipMemoryTypeDevice && at.device != ctx->device)
+            return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_frame_stats_noalloc: out_dev is memory of device " + std::to_string(at.device) +
+                                                     ", the context renders on device " + std::to_string(ctx->device));
+        // a registered host buffer may be mapped at a device address that differs from its host address
+        if (at.devicePointer) out_dev = static_cast<rt_frame_stats*>(at.devicePointer);
+        else if (at.type != hipMemoryTypeDevice)
+            return rt_fail(ctx, RT_ERR_INVALID_ARG, "rt_frame_stats_noalloc: out_dev has no device address");
     }
     const DevLaunch L = makeLaunch(ctx);
     const long long waves = (long long)L.ownedTiles * (L.tileSize / 8) * (L.tileSize / 8);

@@ -3101,6 +3101,7 @@ extern "C" hipError_t RT_SYM(rt_launch_megakernel)(const DevScene* S, const rt_p
                                                    void* accum, void* out, DevCounters* counters, int countBuild,
                                                    int statsOnly, hipStream_t stream)
 {
+    (void)hipGetLastError();      // an error left behind by an earlier, unrelated HIP call is not this launch's
     const int wavesX = L->tileSize / 8;
     const long long blocks = (long long)L->ownedTiles * wavesX * wavesX;
     if (blocks <= 0) return hipSuccess;
@@ -3119,6 +3120,7 @@ extern "C" hipError_t RT_SYM(rt_launch_megakernel)(const DevScene* S, const rt_p
 extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_push_constants* pc, const DevLaunch* L,
                                                    void* accum, void* out, int pixelPairs, void* partial, hipStream_t stream)
 {
+    (void)hipGetLastError();      // an error left behind by an earlier, unrelated HIP call is not this launch's
     const int wavesX = L->tileSize / 8;
     if (pixelPairs && (L->tileSize & 15)) return hipErrorInvalidValue;      // 8 x 16 pixel footprints need whole 16-row bands
     const long long waves = (long long)L->ownedTiles * wavesX * (pixelPairs ? wavesX / 2 : wavesX);
@@ -3153,6 +3155,7 @@ extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_p
 
 extern "C" hipError_t RT_SYM(rt_launch_resolve)(const void* accum, void* out, size_t pixels, float multiplier, hipStream_t stream)
 {
+    (void)hipGetLastError();      // an error left behind by an earlier, unrelated HIP call is not this launch's
     if (pixels == 0) return hipSuccess;
     size_t blocks = (pixels + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -3166,6 +3169,7 @@ extern "C" hipError_t RT_SYM(rt_launch_schedkernel)(const DevScene* S, const rt_
                                                     int statsOnly, unsigned long long* queue, int blocks, hipStream_t stream,
                                                     unsigned long long* diag)
 {
+    (void)hipGetLastError();      // an error left behind by an earlier, unrelated HIP call is not this launch's
     if (L->ownedTiles <= 0 || blocks <= 0) return hipSuccess;
     const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2);
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
@@ -3188,6 +3192,7 @@ extern "C" hipError_t RT_SYM(rt_launch_wf_path)(const DevScene* S, const rt_push
                                                 int countBuild, int statsOnly, int round, int inlineWalks, int blocks,
                                                 hipStream_t stream)
 {
+    (void)hipGetLastError();      // an error left behind by an earlier, unrelated HIP call is not this launch's
     if (L->ownedTiles <= 0 || blocks <= 0) return hipSuccess;
     const size_t lds = inlineWalks ? (size_t)S->stackDepth * 64 * sizeof(uint2) : 0;
     dim3 grid((unsigned)blocks), block(64);
@@ -3212,6 +3217,7 @@ extern "C" hipError_t RT_SYM(rt_launch_wf_path)(const DevScene* S, const rt_push
 extern "C" hipError_t RT_SYM(rt_launch_wf_walk)(const DevScene* S, const rt_push_constants* pc, const DevWavefront* W,
                                                 int countBuild, int round, int blocks, hipStream_t stream)
 {
+    (void)hipGetLastError();      // an error left behind by an earlier, unrelated HIP call is not this launch's
     if (blocks <= 0) return hipSuccess;
     const size_t lds = (size_t)(S->stackDepth < RT_WF_LDS_LEVELS ? S->stackDepth : RT_WF_LDS_LEVELS) * 64 * sizeof(uint2);
     dim3 grid((unsigned)blocks), block(64);
@@ -3224,6 +3230,7 @@ extern "C" hipError_t RT_SYM(rt_launch_wf_walk)(const DevScene* S, const rt_push
 
 extern "C" hipError_t RT_SYM(rt_launch_math)(int which, const float* x, float* y, size_t n, hipStream_t stream)
 {
+    (void)hipGetLastError();      // an error left behind by an earlier, unrelated HIP call is not this launch's
     if (n == 0) return hipSuccess;
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;

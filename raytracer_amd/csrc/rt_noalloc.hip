@@ -84,6 +84,7 @@ extern "C" long long rt_noalloc_max_waves(void) { return RT_NOALLOC_MAX_WAVES; }
 // partials: the pointer rt_noalloc_scratch returned; out: device-accessible DevCounters.
 extern "C" hipError_t rt_noalloc_sum(const void* partials, int n, void* out, hipStream_t stream)
 {
+    (void)hipGetLastError();      // an error left behind by an earlier, unrelated HIP call is not this launch's
     if (!partials || !out || n < 0 || n > RT_NOALLOC_MAX_WAVES) return hipErrorInvalidValue;
     hipLaunchKernelGGL(rt_sum_partials, dim3(1), dim3(256), 0, stream, static_cast<const DevCounters*>(partials), n,
                        static_cast<DevCounters*>(out));

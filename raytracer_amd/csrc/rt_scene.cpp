@@ -161,6 +161,21 @@ namespace {
 
 // tryParseDouble, tiny_obj_loader.h:891-1021: tinyobj's own decimal reader, not
 // strtod - its rounding decides the float the reference ends up with.
+//
+// This number reader and the face triangulation further down re-express tinyobjloader v2.0.0's, step for step
+// where the byte-exact vertex stream depends on it; tinyobjloader is
+//   Copyright (c) 2012-Present, Syoyo Fujita and many contributors, released under the MIT License:
+//   "Permission is hereby granted, free of charge, to any person obtaining a copy of this software and
+//   associated documentation files (the "Software"), to deal in the Software without restriction,
+//   including without limitation the rights to use, copy, modify, merge, publish, distribute,
+//   sublicense, and/or sell copies of the Software, and to permit persons to whom the Software is
+//   furnished to do so, subject to the following conditions: The above copyright notice and this
+//   permission notice shall be included in all copies or substantial portions of the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT
+//   NOT LIMITED TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND
+//   NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES
+//   OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN
+//   CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE."
 bool parseDecimal(const char* p, const char* end, double& value)
 {
     if (p >= end) return false;

@@ -264,8 +264,12 @@ __device__ __forceinline__ V3 ray_colour_team(const DevScene& S, const rt_push_c
 // RayColour for scenes whose GetHit does not depend on the visiting order (DevScene::orderFree). Per
 // bounce the wave hands BOTH rays it has to trace - the shadow ray of the hit just shaded and the
 // scattered ray - to the walkers first (every BVH parent whose box a ray can enter, in one job per ray),
-// tests the leaf parents itself while the walkers work, then waits once and merges by distance (on a
-// tie the parent that comes first in the scene wins, as in the ordered loop). The sun term of a hit is
+// tests the leaf parents itself while the walkers work, then waits once and merges by distance. Both groups
+// are gone through in the any-hit order (leaf parents, BVH parents, each sorted towards the sun), so two
+// parents that are hit at exactly the same distance are decided by that order inside a group and by the
+// object index between the groups - not always as the scene-order loop decides them: such ties are the
+// near-first flavour's stated tolerance, and the only case in which this kernel's image can differ from
+// the lock-step kernels' near-first image. The sun term of a hit is
 // added when its shadow ray's answer is in, one iteration later, still before anything the next hit
 // adds: the additions to `result` keep the reference's order.
 __device__ __forceinline__ V3 ray_colour_team_async(const DevScene& S, const rt_push_constants& pc, Ray ray, bool alive, uint32_t seed,
@@ -645,21 +649,40 @@ __global__ __launch_bounds__(RT_TEAM_WAVES * 64) void RT_SYM(rt_teamkernel)(DevS
     if (lane == 0) __hip_atomic_fetch_add(&sh.ctrl[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+#if defined(RT_FLAVOUR_STRICT)
+// LDS a workgroup of the team kernel needs: control words, ring, job slots of the path waves, the walkers' traversal stacks
+extern "C" size_t rt_team_lds_bytes(int stackDepth, int walkers)
+{
+    const int pathWaves = RT_TEAM_WAVES - walkers;
+    return 64 + RT_TEAM_RING * sizeof(int) + 64 + (size_t)pathWaves * RT_TEAM_SLOTS * (RT_TEAM_IN + RT_TEAM_OUT) * 64 * sizeof(float) +
+           (size_t)walkers * (size_t)stackDepth * 64 * sizeof(uint2);
+}
+#else
+extern "C" size_t rt_team_lds_bytes(int stackDepth, int walkers);
+#endif
+
 extern "C" hipError_t RT_SYM(rt_launch_teamkernel)(const DevScene* S, const rt_push_constants* pc, const DevLaunch* L, void* accum, void* out,
                                                    unsigned long long* queue, int workgroups, int walkers, int refillMin, hipStream_t stream)
 {
+    (void)hipGetLastError();      // an error left behind by an earlier, unrelated HIP call is not this launch's
     const int wavesX = L->tileSize / 8;
     const long long waves = (long long)L->ownedTiles * wavesX * wavesX;
     if (waves <= 0 || workgroups <= 0) return hipSuccess;
     if (walkers < 1 || walkers > RT_TEAM_WAVES - 1) return hipErrorInvalidValue;
     const int pathWaves = RT_TEAM_WAVES - walkers;
-    const size_t lds = 64 + RT_TEAM_RING * sizeof(int) + 64 + (size_t)pathWaves * RT_TEAM_SLOTS * (RT_TEAM_IN + RT_TEAM_OUT) * 64 * sizeof(float) +
-                       (size_t)walkers * (size_t)S->stackDepth * 64 * sizeof(uint2);
+    const size_t lds = rt_team_lds_bytes(S->stackDepth, walkers);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(RT_SYM(rt_teamkernel)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    // the attribute is raised once per size (per device: the largest size asked for so far)
+    static thread_local size_t ldsSet[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (lds > ldsSet[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(RT_SYM(rt_teamkernel)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        ldsSet[dev] = lds;
+    }
     const long long need = (waves + pathWaves - 1) / pathWaves;
     const unsigned grid = (unsigned)(need < workgroups ? need : workgroups);
     hipLaunchKernelGGL(RT_SYM(rt_teamkernel), dim3(grid), dim3(RT_TEAM_WAVES * 64), lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out, queue,

@@ -536,7 +536,7 @@ def test_wavefront_knobs_do_not_change_results(R, default_scene_arrays):
         ref_stats = r.frame_stats(to_pc(R, opc))
         r.set_option(R.RT_OPT_PIPELINE, 2)
         for rounds, refill, waves, walk, parts in [(0, 16, 12, 12, 1), (1, 64, 12, 24, 2), (2, 1, 3, 1, 3), (5, 16, 12, 12, 3),
-                                                   (12, 32, 16, 32, 8), (30, 48, 1, 5, 4)]:
+                                                   (12, 32, 16, 32, 3), (30, 48, 1, 5, 2)]:
             r.set_option(R.RT_OPT_WF_ROUNDS, rounds); r.set_option(R.RT_OPT_WF_REFILL, refill)
             r.set_option(R.RT_OPT_WAVES_PER_CU, waves); r.set_option(R.RT_OPT_WF_WALK_WAVES, walk)
             r.set_option(R.RT_OPT_WF_PARTS, parts)
@@ -546,6 +546,9 @@ def test_wavefront_knobs_do_not_change_results(R, default_scene_arrays):
             st = r.frame_stats(to_pc(R, opc))
             assert (st.rays, st.bvhNodeTests, st.triangleTests, st.samples) == \
                    (ref_stats.rays, ref_stats.bvhNodeTests, ref_stats.triangleTests, ref_stats.samples)
+        # more partitions than the process has hardware queues to give them are refused
+        with pytest.raises(R.RtError):
+            r.set_option(R.RT_OPT_WF_PARTS, 4)
         # fewer parents than uploaded: shadow rays keep the scene order, walks start at parent 0
         opc["parentBVHCount"] = 5; opc["raysPerPixel"] = 1
         r.set_option(R.RT_OPT_WF_ROUNDS, 5); r.set_option(R.RT_OPT_WF_REFILL, 16); r.set_option(R.RT_OPT_WAVES_PER_CU, 12)

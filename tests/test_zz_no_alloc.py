@@ -63,6 +63,22 @@ def test_frame_stats_noalloc_matches_allocating_entry_point(default_scene_arrays
             parts.append(dev_out.cpu().numpy().copy())
         assert tuple(int(v) for v in parts[0] + parts[1]) == want
         r.set_option(R.RT_OPT_TILE_RANK, 0); r.set_option(R.RT_OPT_TILE_WORLD, 1); r.set_option(R.RT_OPT_TILE_SIZE, 64)
+        # a host buffer registered after the fact (hipHostRegister): the kernels get its device address
+        rt = torch.cuda.cudart()
+        if hasattr(rt, "cudaHostRegister"):
+            import mmap
+            pages = mmap.mmap(-1, 4 * mmap.PAGESIZE)                # page-aligned, whole pages
+            raw = np.frombuffer(pages, dtype=np.int64)
+            raw[:] = -1
+            err = rt.cudaHostRegister(raw.ctypes.data, raw.nbytes, 0)
+            if int(err) == 0:                                       # (a runtime that cannot register this mapping: nothing to check)
+                try:
+                    r.frame_stats_noalloc(pc, raw.ctypes.data)
+                    r.sync()
+                    assert tuple(int(v) for v in raw[:4]) == want
+                finally:
+                    rt.cudaHostUnregister(raw.ctypes.data)
+            del raw
         # refusals: pageable host memory, a dispatch with more waves than the array has slots
         plain = np.zeros(4, np.int64)
         with pytest.raises(R.RtError) as e:
