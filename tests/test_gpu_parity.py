@@ -305,6 +305,58 @@ def test_two_samples_per_lane_bit_exact(R, default_scene_arrays, fused):
         r.close()
 
 
+def _zeno_obj(path, n):
+    """n triangles, each half as far from the origin and half as large as the one before: the midpoint builder
+    splits one triangle off per level, so the tree is n - 2 levels deep."""
+    with open(path, "w") as f:
+        for k in range(n):
+            x = 2.0 ** (1 - k); s = x / 4
+            f.write("v %.9g 0 0\nv %.9g %.9g 0\nv %.9g 0 %.9g\n" % (x - s / 3, x - s / 3, s, x + 2 * s / 3, s))
+        for k in range(n):
+            f.write("f %d %d %d\n" % (3 * k + 1, 3 * k + 2, 3 * k + 3))
+
+
+def test_deepest_tree_the_stack_allows(R, tmp_path):
+    """A model whose tree is 31 levels deep - all the shader's `int stack[32]` (raytrace.comp:523) can take -
+    on every pipeline, bit-exact against the oracle (pipeline 4, whose walkers' stacks no longer fit a
+    workgroup's LDS at this depth, hands the launch to the lock-step kernels); the near-first flavour within
+    its bars; one level more is refused at upload."""
+    import shutil
+    for name in ("flat_quad.obj",):
+        shutil.copy(os.path.join(O.MODELS_DIR, name), tmp_path / name)
+    _zeno_obj(str(tmp_path / "zeno33.obj"), 33)
+    _zeno_obj(str(tmp_path / "zeno34.obj"), 34)
+    materials = [scenes.mat((0.5, 0.5, 0.5)), scenes.mat((0.8, 0.3, 0.2)), scenes.mat((0.9, 0.9, 0.9), smoothness=1.0)]
+    objects = [("flat_quad.obj", (0, -0.5, 0), (0, 0, 0), (12, 12, 12), 0),
+               ("zeno33.obj", (-1.5, 0.0, -1.0), (0, 20, 0), (1.5, 1.5, 1.5), 1),
+               ("zeno33.obj", (0.5, 0.2, 0.5), (30, -70, 10), (1.0, 1.0, 1.0), 2)]
+    arrays = scenes.build_oracle(materials, objects, models_dir=str(tmp_path)).bindings()
+    W, H = 192, 112
+    opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 1.5, 4.0), look=(0.0, -0.3, -1.0), fov=60.0)
+    want = oracle_frames(arrays, opc, [0, 1, 2], W, H)
+    assert np.any(want["accum"][..., :3] > 0)
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(arrays)
+        assert r.get_option(R.RT_INFO_STACK_DEPTH) == 31
+        for pipeline in (0, 1, 2, 3, 4):
+            r.set_option(R.RT_OPT_PIPELINE, pipeline)
+            acc, out = gpu_frames(R, r, opc, [0, 1, 2], W, H)
+            assert np.array_equal(bits(acc), bits(want["accum"])) and np.array_equal(bits(out), bits(want["out"])), pipeline
+        for pipeline in (3, 0, 4):
+            r.set_option(R.RT_OPT_PIPELINE, pipeline)
+            r.set_option(R.RT_OPT_TRAVERSAL, 1)
+            acc, out = gpu_frames(R, r, opc, [0, 1, 2], W, H)
+            assert within(acc[..., :3], want["accum"][..., :3]) >= 0.995, pipeline
+            r.set_option(R.RT_OPT_TRAVERSAL, 0)
+        deep = scenes.build_oracle(materials, [("zeno34.obj", (0, 0, 0), (0, 0, 0), (1, 1, 1), 1)], models_dir=str(tmp_path)).bindings()
+        with pytest.raises(R.RtError) as e:
+            r.upload_scene(deep)
+        assert e.value.code == -6 and "31 levels" in str(e.value)
+    finally:
+        r.close()
+
+
 def test_empty_scene_is_all_sky(R):
     arrays = [np.zeros(0, d) for d in O.BINDING_DTYPES]
     r = R.Renderer(0)
