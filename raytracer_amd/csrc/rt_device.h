@@ -122,7 +122,7 @@ struct DevScene {
      * object roots index this array and `nodes` is unused). wideLdsLevels = traversal-stack entries a lane
      * keeps in LDS; deeper ones go to the lane's private memory. */
     const DevNode4*    nodes4;
-    int32_t            wideLdsLevels;
+    int32_t            wideLdsLevels;   /* (unused) */
     int32_t            wideStackNeed;   /* entries a lane can need in the worst case */
     /* Runs of consecutive BVH parents: runLen[p] = number of BVH parents (root >= 0) that follow one another
      * from position p of the scene order on, at most 64 (0 where position p holds none); runLenAny the same

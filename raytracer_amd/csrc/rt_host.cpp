@@ -624,8 +624,10 @@ int ensureFastScene(rt_ctx* ctx)
             w.tlasBase = tlasBase;
             w.nearFirstBase = 0;
             w.wideStackNeed = need;
-            w.wideLdsLevels = std::min(need + 1, RT_WIDE_LDS_LEVELS);      // (the branch-free push writes one slot ahead)
-            w.stackDepth = w.wideLdsLevels;
+            // entries a lane can need, one more because the branch-free push writes one slot ahead; how many of them live in
+            // LDS is the kernels' business (the launcher clamps to the level count the kernels were compiled with)
+            w.stackDepth = need + 1;
+            w.wideLdsLevels = 0;
             ctx->wideScene = w;
             ctx->wideNodeCount = nodes4.size();
             ctx->hWideObjects = wide;

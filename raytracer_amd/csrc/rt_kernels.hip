@@ -1187,7 +1187,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
                     }
                 }
                 if (goF) {
-                    if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(nv.ES)); ++sp; }
+                    if (canS) wide_push(wlds, wdeep, sp, refs.y, nv.ES);
                     cur = refs.x;
                 } else if (canS && (bw.closest > nv.ES)) {
                     cur = refs.y;
@@ -1195,7 +1195,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
                     cur = RT_NONE;
                     while (sp > 0) {
                         --sp;
-                        const uint2 e = stack[sp * 64];
+                        const uint2 e = wide_top(wlds, wdeep, sp);
                         if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
                     }
                 }
@@ -1215,7 +1215,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
                 if (stop) sp = 0;
                 while (sp > 0) {
                     --sp;
-                    const uint2 e = stack[sp * 64];
+                    const uint2 e = wide_top(wlds, wdeep, sp);
                     if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
                 }
             }
@@ -1406,6 +1406,8 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
         int cur = root, sp = 0;
         const bool nearFirst = NF == 1 && root >= S.nearFirstBase;   // wave-uniform: a rebuilt tree, nearer child first
         if (NF >= 2) continue;      // not reached: every BVH parent of a wide scene is in a run or under the hierarchy
+        lds_uint2* const wlds = (lds_uint2*)stack;
+        WideDeep wdeep;
         for (;;) {
             int budget = RT_DESCENT_CAP;
             while ((unsigned)cur < (unsigned)RT_NONE && budget-- > 0) {
@@ -1422,7 +1424,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
                     }
                 }
                 if (goF) {
-                    if (canS) { stack[sp * 64] = make_uint2((uint32_t)refs.y, __float_as_uint(nv.ES)); ++sp; }
+                    if (canS) wide_push(wlds, wdeep, sp, refs.y, nv.ES);
                     cur = refs.x;
                 } else if (canS && (bw.closest > nv.ES)) {
                     cur = refs.y;
@@ -1430,7 +1432,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
                     cur = RT_NONE;
                     while (sp > 0) {
                         --sp;
-                        uint2 e = stack[sp * 64];
+                        uint2 e = wide_top(wlds, wdeep, sp);
                         if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
                     }
                 }
@@ -1450,7 +1452,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
                 if (stop) sp = 0;
                 while (sp > 0) {
                     --sp;
-                    uint2 e = stack[sp * 64];
+                    uint2 e = wide_top(wlds, wdeep, sp);
                     if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
                 }
             }
@@ -1693,7 +1695,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
 #endif
     RT_SEC_BEGIN(secKernel);
     RT_WORK_BEGIN();
-    constexpr bool RES = NF >= 2;
+    constexpr bool RES = true;
     float* const res = reinterpret_cast<float*>(stackMem + S.stackDepth * 64) + lane;      // (wide kernels: LDS-resident path state)
 
     const int wavesX = L.tileSize >> 3;
@@ -1825,7 +1827,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WAVE
 #endif
     RT_SEC_BEGIN(secKernel);
     RT_WORK_BEGIN();
-    constexpr bool RES = NF >= 2;
+    constexpr bool RES = true;
     float* const res = reinterpret_cast<float*>(stackMem + S.stackDepth * 64) + lane;      // (wide kernels: LDS-resident path state)
 
     const int wavesX = L.tileSize >> 3;
@@ -3130,9 +3132,9 @@ extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_p
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // wide scenes: the walk keeps RT_WIDE_LDS_LEVELS entries of a lane's stack in LDS (deeper ones in private memory), the LDS-resident path state behind them
     DevScene scene = *S;
-    if (scene.nodes4 != nullptr && scene.stackDepth > RT_WIDE_LDS_LEVELS) scene.stackDepth = RT_WIDE_LDS_LEVELS;
+    if (scene.stackDepth > RT_WIDE_LDS_LEVELS) scene.stackDepth = RT_WIDE_LDS_LEVELS;
     S = &scene;
-    const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2) + (S->nodes4 != nullptr ? (size_t)RT_RES_DWORDS * 64 * sizeof(float) : 0);
+    const size_t lds = (size_t)S->stackDepth * 64 * sizeof(uint2) + (size_t)RT_RES_DWORDS * 64 * sizeof(float);
     const dim3 grid((unsigned)blocks), block(64);
     // <true> knows rebuilt trees (near-first traversal), <false> has that handling compiled out
     // <2> walks four-child records (the wide twin of an order-free near-first scene)
