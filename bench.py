@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=-1, help="RT_OPT_PIPELINE to measure (-1 = the library's default)")
     ap.add_argument("--trace", type=int, default=0, help="1 = stage markers on stderr")
     ap.add_argument("--stage-timeout", type=float, default=600.0, help="seconds a stage (set-up, warm-up, timed steps) may take before the watchdog ends the process")
+    ap.add_argument("--count-work", type=int, default=1, help="1 = at N = 1 count the timed kernel's own box / triangle tests with the counter build, in a child process "
+                                                              "after the timed region (0 for profiling runs, which should hold one process)")
     ap.add_argument("--single-dispatch", type=int, default=0,
                     help="1 = also time the frames as ONE dispatch with raysPerPixel = frames (extra launches of the same kernel: off by "
                          "default so that a profile of the default run holds only the timed launches)")
@@ -409,7 +411,7 @@ def main():
         # the work the TIMED kernel does (its own trees and order), counted by the counter build of the same kernels
         # over the frames of one step (up to 64, scaled beyond); reference order: the counting kernel's figures are it
         done = None
-        if world == 1 and pipeline == 3:
+        if world == 1 and pipeline == 3 and args.count_work:
             cf = min(frames_rank, 64)
             cw = count_timed_work(args.config, args.traversal, cf)
             if cw is not None:

@@ -1,93 +1,120 @@
-"""Collects what scripts/prof.sh, scripts/traffic.sh and scripts/pmc.sh left under gpurun_out/ into profiles/:
-usage: assemble_profiles.py <tag>   (e.g. r02_b: reads gpurun_out/prof_<tag>, gpurun_out/traffic_*.json, gpurun_out/pmc_r02_*.txt)"""
+"""Collects what scripts/profile_round.sh <tag> left under gpurun_out/ into profiles/:
+  <tag>_kernel_stats.csv, <tag>_bench.json      kernel trace of the default bench.py command and the line it printed
+  hbm_traffic.json                              FETCH_SIZE x 2 + WRITE_SIZE per launch (one entry per kernel, configuration and
+                                                flavour, keyed on the hash of the kernel sources), with the issue statistics of
+                                                the SQ passes attached where they were taken - what bench.py reports as
+                                                roofline.traffic / valu_busy / lane_util
+  <tag>_pmc.txt                                 the counter passes with the derived figures
+  <tag>_wf_<config>_p<pipeline>_kernel_stats.csv   kernel traces of the wavefront pipeline (2), the path / walker waves (4), kernel 0
+  <tag>_bench_cfg<config>.json                  the bench line of every configuration
+usage: assemble_profiles.py <tag>"""
 import csv, glob, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 tag = sys.argv[1]
 
-shutil.copy(os.path.join(G, "prof_" + tag, "kernel_stats.csv"), os.path.join(P, tag + "_kernel_stats.csv"))
-bench_line = open(os.path.join(G, "prof_" + tag, "bench.json")).read().strip().splitlines()[-1]
-open(os.path.join(P, tag + "_bench.json"), "w").write(bench_line + "\n")
-bench = json.loads(bench_line)
-
-entries = []
-for f in sorted(glob.glob(os.path.join(G, "traffic_*.json"))):
-    entries += json.load(open(f))["entries"]
-shas = {e["kernels_sha256"] for e in entries}
-newest = max(entries, key=lambda e: os.path.getmtime(os.path.join(G, "traffic_%s_%d.json" % (e["config"], e["traversal"]))))["kernels_sha256"]
-entries = [e for e in entries if e["kernels_sha256"] == newest]       # one kernel source per file
-json.dump({"entries": entries}, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
-
 
 def rows(name):
     out = {}
-    for line in open(os.path.join(G, name)).read().splitlines():
+    path = os.path.join(G, name)
+    if not os.path.exists(path):
+        return out
+    for line in open(path).read().splitlines():
         m = re.match(r"(.*?)\s+(\S+)\s+sum (\S+)\s+per-dispatch (\S+) \(n=(\d+)\)", line)      # kernel names may hold spaces
-        if m:
+        if m and "rt_pairkernel" in m.group(1):
             out[m.group(2)] = float(m.group(4))
     return out
 
 
-nf, ro = {}, {}
-for f in ("pmc_r02_nf_a.txt", "pmc_r02_nf_b.txt", "pmc_r02_nf_c.txt"):
-    nf.update(rows(f))
-for f in ("pmc_r02_ro_a.txt", "pmc_r02_ro_b.txt"):
-    ro.update(rows(f))
+def derived(c):
+    """Issue statistics of one launch from the SQ / TCP / TCC passes (dict counter -> value of the largest launch)."""
+    d = {}
+    if "SQ_BUSY_CYCLES" in c and "SQ_INSTS_VALU" in c:
+        busy = c["SQ_BUSY_CYCLES"] / 32                      # summed over 32 shader engines
+        d["busy_cycles"] = busy
+        d["valu_busy"] = c["SQ_INSTS_VALU"] * 2 / (busy * 1024)      # a wave64 instruction occupies its SIMD for two cycles; 1024 SIMDs
+    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+        d["lane_util"] = c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"])
+    if "SQ_WAVE_CYCLES" in c and "SQ_ACTIVE_INST_ANY" in c:
+        d["wave_issuing"] = c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"]
+        d["wave_stalled_at_issue"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]
+        d["wave_waiting"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+        d["l1_hit"] = 1 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    if "TCC_HIT_sum" in c:
+        d["l2_hit"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if "TA_TA_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c:
+        d["ta_busy"] = c["TA_TA_BUSY_sum"] / 256 / (c["GRBM_GUI_ACTIVE"] / 8)
+    for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS"):
+        if k in c:
+            d[k.lower()] = c[k]
+    return d
 
-stats = {}
-for row in csv.DictReader(open(os.path.join(P, tag + "_kernel_stats.csv"))):
-    stats[row["Name"].split("(")[0].replace("void ", "")] = row
-kt, kf = stats["rt_pairkernel_strict<true>"], stats["rt_pairkernel_strict<false>"]
-tr = {(e["config"], e["traversal"]): e for e in entries}
-t11, t10 = tr[("1", 1)], tr[("1", 0)]
-ms_t, ms_f = float(kt["AverageNs"]) / 1e6, float(kf["AverageNs"]) / 1e6
-busy = nf["SQ_BUSY_CYCLES"] / 32
 
-L = []
-L.append("rocprofv3 --pmc, rt_pairkernel_strict (two samples of a pixel per lane, 8 consecutive frames per launch), default scene")
-L.append("2560x1369, 1 ray/pixel per frame, per LAUNCH of 8 frames (mean of 2), MI355X. <true>: near-first traversal of the rebuilt")
-L.append("trees (the benchmark's headline flavour); in brackets <false>: reference order (bit-exact with the oracle).")
-L.append("One pass per group (scripts/pmc.sh <tag> \"<counters>\" 16 2560 1369 0 3 full <traversal>):")
-L.append("  a: SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES")
-L.append("  b: SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA")
-L.append("  c: TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE TA_TA_BUSY_sum   (near-first only)")
-L.append("  FETCH_SIZE / WRITE_SIZE: scripts/traffic.sh (profiles/hbm_traffic.json)")
-L.append("")
-for k in ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
-          "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY",
-          "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"]:
-    extra = "   %+.1f %%" % (100.0 * (nf[k] / ro[k] - 1.0)) if k in ro and k != "SQ_WAVES" else ""
-    L.append("%-30s %.5e   [%s]%s" % (k, nf[k], ("%.5e" % ro[k]) if k in ro else "-", extra))
-L.append("FETCH_SIZE                     %.5e KB (x2 on gfx950 -> %.2f GB)   [%.5e KB -> %.2f GB]" % (
-    t11["fetch_size_kb"], 2 * t11["fetch_size_kb"] * 1024 / 1e9, t10["fetch_size_kb"], 2 * t10["fetch_size_kb"] * 1024 / 1e9))
-L.append("WRITE_SIZE                     %.5e KB (%.2f GB)                   [%.5e KB -> %.2f GB]" % (
-    t11["write_size_kb"], t11["write_size_kb"] * 1024 / 1e9, t10["write_size_kb"], t10["write_size_kb"] * 1024 / 1e9))
-L.append("")
-L.append("derived (near-first):")
-L.append("  kernel time %.2f ms per launch of 8 frames = %.2f ms per frame (rocprofv3 --kernel-trace --stats, profiles/%s_kernel_stats.csv:" % (ms_t, ms_t / 8, tag))
-L.append("  %s launches of rt_pairkernel_strict<true>, min %.2f max %.2f; bench.py's HIP events: %.2f); reference order %.2f ms" % (
-    kt["Calls"], float(kt["MinNs"]) / 1e6, float(kt["MaxNs"]) / 1e6, bench["roofline"]["launch_ms"], ms_f))
-L.append("  (%s launches of <false>, min %.2f max %.2f; HIP events %.2f)" % (kf["Calls"], float(kf["MinNs"]) / 1e6, float(kf["MaxNs"]) / 1e6,
-                                                                           bench["other_flavour"]["launch_ms"]))
-L.append("  SQ_BUSY_CYCLES / 32 shader engines = %.3e cycles = %.1f ms at 2.4 GHz" % (busy, busy / 2.4e6))
-L.append("  vector-ALU issue: SQ_INSTS_VALU x 2 cycles (a wave64 instruction occupies its SIMD-32 for two) / (cycles x 1024 SIMDs) = %.1f %%" % (
-    100 * nf["SQ_INSTS_VALU"] * 2 / (busy * 1024)))
-L.append("  lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = %.1f %%   [%.1f %%]" % (
-    100 * nf["SQ_THREAD_CYCLES_VALU"] / (64 * nf["SQ_ACTIVE_INST_VALU"]), 100 * ro["SQ_THREAD_CYCLES_VALU"] / (64 * ro["SQ_ACTIVE_INST_VALU"])))
-L.append("  a wave's time: issuing %.1f %%, stalled at issue %.1f %%, parked on a wait %.1f %%   [%.1f / %.1f / %.1f]" % (
-    100 * nf["SQ_ACTIVE_INST_ANY"] / nf["SQ_WAVE_CYCLES"], 100 * nf["SQ_WAIT_INST_ANY"] / nf["SQ_WAVE_CYCLES"], 100 * nf["SQ_WAIT_ANY"] / nf["SQ_WAVE_CYCLES"],
-    100 * ro["SQ_ACTIVE_INST_ANY"] / ro["SQ_WAVE_CYCLES"], 100 * ro["SQ_WAIT_INST_ANY"] / ro["SQ_WAVE_CYCLES"], 100 * ro["SQ_WAIT_ANY"] / ro["SQ_WAVE_CYCLES"]))
-L.append("  vector L1 hit rate = 1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES = %.1f %%; texture addressers busy %.0f %% of the launch" % (
-    100 * (1 - nf["TCP_TCC_READ_REQ_sum"] / nf["TCP_TOTAL_CACHE_ACCESSES_sum"]), 100 * nf["TA_TA_BUSY_sum"] / 256 / (nf["GRBM_GUI_ACTIVE"] / 8)))
-L.append("  HBM traffic %.2f GB per launch = %.0f GB/s, %.1f %% of the HBM peak; the write half is the spilled path state: %.1e wave-level" % (
-    t11["bytes_per_launch"] / 1e9, t11["bytes_per_launch"] / 1e9 / (ms_t * 1e-3), 100 * t11["bytes_per_launch"] / 1e9 / (ms_t * 1e-3) / 8000, nf["SQ_INSTS_VMEM_WR"]))
-L.append("  stores per launch = about %.0f registers stored (and loaded back) around each of the ~1.8e6 wave-level GetHit calls" % (nf["SQ_INSTS_VMEM_WR"] / 1.8e6))
-L.append("  (56 320 waves x 4 pairs of samples x up to 4 bounces x 2 calls), outside the walk loops.")
-L.append("  Near-first against reference order: %.0f %% fewer vector instructions, %.0f %% fewer vector loads, the same lane utilisation:" % (
-    100 * (1 - nf["SQ_INSTS_VALU"] / ro["SQ_INSTS_VALU"]), 100 * (1 - nf["SQ_INSTS_VMEM_RD"] / ro["SQ_INSTS_VMEM_RD"])))
-L.append("  the rebuilt trees and the ordering shorten every walk, they do not make the lanes of a wave agree.")
-open(os.path.join(P, tag + "_pmc_pairs.txt"), "w").write("\n".join(L) + "\n")
-print("\n".join(L[9:]))
-print("traffic entries:", [(e["config"], e["traversal"], round(e["bytes_per_launch"] / 1e9, 2)) for e in entries])
-print("bench:", bench["value"], bench["ms_per_frame"], bench["roofline"]["frac"], bench["roofline"]["traffic"], bench["other_flavour"]["value"])
+# kernel trace + bench line of the default command
+src = os.path.join(G, "prof_" + tag)
+bench = None
+if os.path.exists(os.path.join(src, "kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(P, tag + "_kernel_stats.csv"))
+    line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
+    open(os.path.join(P, tag + "_bench.json"), "w").write(line + "\n")
+    bench = json.loads(line)
+
+# counter passes
+pmc = {}
+for cfg, trav in (("1", 1), ("1", 0), ("4s", 1)):
+    c = {}
+    for part in "abc":
+        c.update(rows("pmc_%s_%s_%d_%s.txt" % (tag, cfg, trav, part)))
+    if c:
+        pmc[(cfg, trav)] = (c, derived(c))
+
+# traffic entries (newest sources only), PMC summary attached
+entries = []
+for f in sorted(glob.glob(os.path.join(G, "traffic_*.json"))):
+    entries += json.load(open(f))["entries"]
+entries = [e for e in entries if "sources_sha256" in e]
+if entries:
+    newest = max(entries, key=lambda e: os.path.getmtime(os.path.join(G, "traffic_%s_%d.json" % (e["config"], e["traversal"]))))["sources_sha256"]
+    entries = [e for e in entries if e["sources_sha256"] == newest]
+    for e in entries:
+        key = (str(e["config"]), e["traversal"])
+        if key in pmc and "rt_pairkernel" in e["kernel"]:
+            e["pmc"] = pmc[key][1]
+    json.dump({"entries": entries}, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=1)
+
+# the counter passes as text
+names = {1: "near-first", 0: "reference order"}
+L = ["rocprofv3 --pmc passes of rt_pairkernel_strict (two samples of a pixel per lane), per LAUNCH (the largest of the run: 32 frames of",
+     "configs[1], 16 of the 1M-triangle scene, rendered in pieces of two frames), one pass per counter group (scripts/pmc_cfg.sh), MI355X.", ""]
+for (cfg, trav), (c, d) in pmc.items():
+    L.append("config %s, %s" % (cfg, names[trav]))
+    for k in sorted(c):
+        L.append("  %-30s %.5e" % (k, c[k]))
+    tr = [e for e in entries if str(e["config"]) == cfg and e["traversal"] == trav and "rt_pairkernel" in e["kernel"]]
+    if tr:
+        t = tr[0]
+        L.append("  FETCH_SIZE x 2 %.3f GB, WRITE_SIZE %.3f GB, with the pieces' sum kernel %.3f GB per launch" % (
+            2 * t["fetch_size_kb"] * 1024 / 1e9, t["write_size_kb"] * 1024 / 1e9, t["bytes_per_launch"] / 1e9))
+    L.append("  derived: " + ", ".join("%s %.3g" % (k, v) for k, v in d.items() if not k.startswith("sq_")))
+    L.append("")
+if pmc:
+    open(os.path.join(P, tag + "_pmc.txt"), "w").write("\n".join(L) + "\n")
+
+# other pipelines
+for d in sorted(glob.glob(os.path.join(G, "wf_%s_*" % tag))):
+    name = os.path.basename(d)[len("wf_%s_" % tag):]
+    if os.path.exists(os.path.join(d, "kernel_stats.csv")):
+        shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(P, "%s_wf_%s_kernel_stats.csv" % (tag, name)))
+        open(os.path.join(P, "%s_wf_%s_run.txt" % (tag, name)), "w").write(open(os.path.join(d, "run.log")).read().strip().splitlines()[-1] + "\n")
+
+# bench lines
+for f in sorted(glob.glob(os.path.join(G, "bench_%s_cfg*.json" % tag))):
+    line = open(f).read().strip().splitlines()[-1]
+    open(os.path.join(P, os.path.basename(f).replace("bench_%s_" % tag, "%s_bench_" % tag)), "w").write(line + "\n")
+
+print("\n".join(L))
+print("traffic entries:", [(e["kernel"], e["config"], e["traversal"], round(e["bytes_per_launch"] / 1e9, 2)) for e in entries])
+if bench:
+    print("bench:", bench["value"], bench["ms_per_frame"], bench["roofline"]["frac"], bench["roofline"]["traffic"], bench["other_flavour"]["value"])

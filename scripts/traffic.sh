@@ -9,8 +9,8 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic_${CFG}_${TRAV}
 rm -rf $OUT && mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 scripts/render_cfg.py $CFG $TRAV $FRAMES > $OUT/fetch.log 2>&1 || exit 1
-timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 scripts/render_cfg.py $CFG $TRAV $FRAMES > $OUT/write.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 scripts/render_cfg.py $CFG $TRAV $FRAMES > $OUT/fetch.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 scripts/render_cfg.py $CFG $TRAV $FRAMES > $OUT/write.log 2>&1 || exit 1
 python3 - "$OUT" "$CFG" "$TRAV" <<'PY'
 import csv, sys, glob, json, hashlib, os, collections
 out, cfg, trav = sys.argv[1], sys.argv[2], int(sys.argv[3])
@@ -40,6 +40,13 @@ for k in fetch:
                     "fetch_size_kb": full_f, "write_size_kb": full_w,
                     "bytes_per_launch": 2.0 * full_f * 1024.0 + full_w * 1024.0,
                     "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x 2 (gfx950), largest launch of the run; " + frames_line})
+# a launch in pieces is two kernels: the pieces' sum belongs to the launch
+by = {e["kernel"]: e for e in entries}
+for name, e in by.items():
+    other = by.get(name.replace("rt_pairkernel", "rt_sum_pieces"))
+    if "rt_pairkernel" in name and other is not None:
+        e["sum_kernel_bytes_per_launch"] = other["bytes_per_launch"]
+        e["bytes_per_launch"] += other["bytes_per_launch"]
 json.dump({"entries": entries}, open(out + ".json", "w"), indent=1)
 print(json.dumps(entries, indent=1))
 PY
