@@ -1,5 +1,6 @@
 """Renders a benchmark configuration the way bench.py's timed region does (for profiling runs).
-usage: render_cfg.py <config 0|1|2|3|4s> <traversal 0|1> [frames] [pipeline] [fast]"""
+usage: render_cfg.py <config 0|1|2|3|4s> <traversal 0|1> [frames] [pipeline] [fast]
+environment: RT_PIECES (RT_OPT_LAUNCH_PIECES), RT_FPL (RT_OPT_FRAMES_PER_LAUNCH)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,6 +16,10 @@ if len(sys.argv) > 4 and int(sys.argv[4]) >= 0:
 if len(sys.argv) > 5:
     r.set_option(R.RT_OPT_FAST_MATH, int(sys.argv[5]))
 r.set_option(R.RT_OPT_TRAVERSAL, trav)
+if os.environ.get("RT_PIECES"):
+    r.set_option(R.RT_OPT_LAUNCH_PIECES, int(os.environ["RT_PIECES"]))
+if os.environ.get("RT_FPL"):
+    r.set_option(R.RT_OPT_FRAMES_PER_LAUNCH, int(os.environ["RT_FPL"]))
 pc = wl["pc"]
 r.render_frames(pc, 0, 1, min(frames, 8)); r.sync()        # warm-up launch (first in the profile)
 r.clear_accumulation()
