@@ -107,7 +107,8 @@ for d in sorted(glob.glob(os.path.join(G, "wf_%s_*" % tag))):
     name = os.path.basename(d)[len("wf_%s_" % tag):]
     if os.path.exists(os.path.join(d, "kernel_stats.csv")):
         shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(P, "%s_wf_%s_kernel_stats.csv" % (tag, name)))
-        open(os.path.join(P, "%s_wf_%s_run.txt" % (tag, name)), "w").write(open(os.path.join(d, "run.log")).read().strip().splitlines()[-1] + "\n")
+        said = [l for l in open(os.path.join(d, "run.log")).read().splitlines() if l.startswith("config ")]
+        open(os.path.join(P, "%s_wf_%s_run.txt" % (tag, name)), "w").write((said[-1] if said else "") + "\n")
 
 # bench lines
 for f in sorted(glob.glob(os.path.join(G, "bench_%s_cfg*.json" % tag))):

@@ -44,7 +44,7 @@ if has variants; then
     OUT=$G/wf_${TAG}_$1_p$2; rm -rf $OUT; mkdir -p $OUT
     (cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 scripts/render_cfg.py $1 $([ $2 = 2 ] && echo 0 || echo 1) 16 $2 > $OUT/run.log 2>&1) || { echo "variant $cp failed"; tail -3 $OUT/run.log; exit 1; }
     find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
-    tail -1 $OUT/run.log
+    grep "^config" $OUT/run.log | tail -1
   done
 fi
 if has bench; then
