@@ -1325,6 +1325,95 @@ __device__ __forceinline__ void walk_tlas_pair(const DevScene& S, V3 oA, V3 dA, 
     }
 }
 
+// The leaf parents (objects that are one leaf: the walls of a room, a floor) of a scene whose hits do not depend on the
+// visiting order, every lane for itself. The wave-uniform loop of trace_pair enters a wall when ANY lane's ray meets its
+// box, and a ray in a closed room meets the boxes of several walls before the one it hits: five of six walls entered per
+// call with a fifth of the lanes busy in each. Here a first pass (still wave-uniform: boxes through scalar loads) gives
+// every ray the wall whose box it enters FIRST, the runner-up and a mask of the rest; then every lane tests its own
+// ray's nearest wall - object record and triangles through per-lane loads - and goes on to the next one only if that box
+// begins in front of the closest hit so far, which for a ray inside a room it almost never does: one test per ray with
+// every lane busy. Walls [base, base + count), count <= 32. A then B, as in the walks.
+#ifndef RT_LANE_WALLS
+#define RT_LANE_WALLS 1
+#endif
+// One ray's walls: candidates (mask of the walls whose boxes it enters in front of its closest hit), the nearest one
+// and the runner-up with the distance at which the runner-up's box begins. k: the wall to test next, -1 none, -2 "measure
+// what is left again".
+struct WallRay { unsigned m; int k, k2; float e2; };
+
+template <bool ANYHIT>
+__device__ __forceinline__ void wall_step(const DevScene& S, int base, WallRay& w, V3 org, V3 dirN, float tMin, Best& best)
+{
+    const DevObject* ob = S.objects + base + w.k;      // per lane
+    const V3 lo = xform(ob->inv, org, 1.0f), ld = normalize3(xform(ob->inv, dirN, 0.0f));
+    const float4* tp = reinterpret_cast<const float4*>(S.tris + ~ob->root);
+    bool hit = false;
+    for (;;) {
+        const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+        if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, base + w.k, best)) { hit = true; if (ANYHIT) break; }
+        if (__float_as_int(t0.w) <= 1) break;
+        tp += 3;
+    }
+    w.m &= ~(1u << w.k);
+    // the next wall of this ray: the runner-up if its box begins in front of the closest hit (nothing else that is left
+    // begins before it); beyond the two nearest the boxes are measured again (rare)
+    int next = -1;
+    if (!(ANYHIT && hit) && w.m != 0) {
+        if (w.k2 >= 0 && (w.m & (1u << w.k2))) { if (best.closest > w.e2) next = w.k2; }
+        else next = -2;
+    }
+    if (next == -1) w.m = 0;
+    w.k = next;
+}
+
+template <bool ANYHIT>
+__device__ __forceinline__ void walls_pair(const DevScene& S, int base, int count, V3 oA, V3 dA, V3 winvA, bool liveA, Best& bA,
+                                           V3 oB, V3 dB, V3 winvB, bool liveB, Best& bB, bool anyParA, bool anyParB, float tMin)
+{
+    float e1A = INFINITY, e1B = INFINITY;
+    WallRay wA, wB;
+    wA.m = 0; wA.k = -1; wA.k2 = -1; wA.e2 = INFINITY;
+    wB = wA;
+    for (int k = 0; k < count; ++k) {
+        const DevObject* ob = S.objects + base + k;      // wave-uniform address
+        if (!(ob->root > RT_REF_LIVE_MIN)) continue;
+        const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+        RT_WORK(0, (liveA ? 1 : 0) + (liveB ? 1 : 0));
+        float E;
+        if (liveA && (anyParA ? lean_box<true>(oA, winvA, bmn, bmx, tMin, E) : lean_box<false>(oA, winvA, bmn, bmx, tMin, E)) && (bA.closest > E)) {
+            wA.m |= 1u << k;
+            if (E < e1A) { wA.e2 = e1A; wA.k2 = wA.k; e1A = E; wA.k = k; }
+            else if (E < wA.e2) { wA.e2 = E; wA.k2 = k; }
+        }
+        if (liveB && (anyParB ? lean_box<true>(oB, winvB, bmn, bmx, tMin, E) : lean_box<false>(oB, winvB, bmn, bmx, tMin, E)) && (bB.closest > E)) {
+            wB.m |= 1u << k;
+            if (E < e1B) { wB.e2 = e1B; wB.k2 = wB.k; e1B = E; wB.k = k; }
+            else if (E < wB.e2) { wB.e2 = E; wB.k2 = k; }
+        }
+    }
+    while (__any((wA.m | wB.m) != 0)) {
+        if (wA.m != 0 && wA.k >= 0) wall_step<ANYHIT>(S, base, wA, oA, dA, tMin, bA);
+        if (wB.m != 0 && wB.k >= 0) wall_step<ANYHIT>(S, base, wB, oB, dB, tMin, bB);
+        if (__any((wA.m != 0 && wA.k == -2) || (wB.m != 0 && wB.k == -2))) {
+            // measure the remaining boxes of the rays that need it again and take the nearest one in front of the closest hit
+            const bool needA = wA.m != 0 && wA.k == -2, needB = wB.m != 0 && wB.k == -2;
+            float eA = INFINITY, eB = INFINITY;
+            int kA = -1, kB = -1;
+            for (int j = 0; j < count; ++j) {
+                const DevObject* ob = S.objects + base + j;      // wave-uniform address
+                const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
+                float E;
+                if (needA && (wA.m & (1u << j)) && (anyParA ? lean_box<true>(oA, winvA, bmn, bmx, tMin, E) : lean_box<false>(oA, winvA, bmn, bmx, tMin, E)) &&
+                    (bA.closest > E) && E < eA) { eA = E; kA = j; }
+                if (needB && (wB.m & (1u << j)) && (anyParB ? lean_box<true>(oB, winvB, bmn, bmx, tMin, E) : lean_box<false>(oB, winvB, bmn, bmx, tMin, E)) &&
+                    (bB.closest > E) && E < eB) { eB = E; kB = j; }
+            }
+            if (needA) { wA.k = kA; wA.k2 = -1; if (kA < 0) wA.m = 0; }
+            if (needB) { wB.k = kB; wB.k2 = -1; if (kB < 0) wB.m = 0; }
+        }
+    }
+}
+
 // GetHit for two rays per lane (see above). onA / onB: the lane has such a ray. ANYHIT: shadow rays,
 // leaf parents first, a ray stops at its first accepted hit.
 // NF: 0 = the reference-order scene (near-first handling compiled out); 1 = the scene holds rebuilt two-child trees
@@ -1342,7 +1431,18 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
     const bool parWA = lean_inverse(dA, winvA) && onA, parWB = lean_inverse(dB, winvB) && onB;
     const bool permute = ANYHIT && parentCount == S.objectCount;
     const bool tightScene = NF != 0;   // the near-first scene: boxes are only culls
-    for (int pos = 0; pos < parentCount; ++pos) {
+    int pos = 0;
+    if (NF >= 2 && RT_LANE_WALLS) {
+        // a wide scene stores its leaf parents first (in both orders): every lane goes through its own rays' walls, nearest first
+        RT_SEC_BEGIN(secWall);
+        for (; pos < S.anyLeafCount; pos += 32) {
+            const bool liveA = onA && !(ANYHIT && bA.object >= 0), liveB = onB && !(ANYHIT && bB.object >= 0);
+            walls_pair<ANYHIT>(S, pos, min(32, S.anyLeafCount - pos), oA, dA, winvA, liveA, bA, oB, dB, winvB, liveB, bB, __any(parWA), __any(parWB), tMin);
+        }
+        pos = S.anyLeafCount;
+        RT_SEC_END(ANYHIT ? 7 : 2, secWall);
+    }
+    for (; pos < parentCount; ++pos) {
         const int i = permute ? S.anyOrder[pos] : pos;
         const DevObject* ob = S.objects + i;   // wave-uniform address
         const bool liveA = onA && !(ANYHIT && bA.object >= 0), liveB = onB && !(ANYHIT && bB.object >= 0);
@@ -1366,6 +1466,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
                 continue;
             }
         }
+        if (NF >= 2 && RT_LANE_WALLS) continue;      // not reached: leaf parents were handled above, BVH parents in runs or under the hierarchy
         RT_WORK(0, (liveA ? 1 : 0) + (liveB ? 1 : 0));
         const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
         float E;

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import raytracer_amd as R
 from raytracer_amd.workloads import build_workload
 wl = build_workload(sys.argv[1] if len(sys.argv) > 1 else "1")
-r = R.Renderer(0); r.upload_scene(wl["scene"].buffers()); r.resize(wl["width"], wl["height"]); r.set_option(R.RT_OPT_PIPELINE, 3)
+r = R.Renderer(0); r.upload_scene(wl["scene"].buffers()); r.resize(wl["width"], wl["height"]); r.set_option(R.RT_OPT_PIPELINE, 3); r.set_option(R.RT_OPT_LAUNCH_PIECES, 0)      # (the timers are read out at the end of a launch in one piece)
 pc = wl["pc"]
 lib = R.load_library()
 out = (C.c_uint64 * 8)()
