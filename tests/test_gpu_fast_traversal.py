@@ -313,3 +313,41 @@ def test_hierarchy_over_the_parents(R):
         assert ok >= 0.995 and same >= 0.99, (same, ok)
     finally:
         r.close()
+
+
+def test_many_leaf_parents_every_lane_for_itself(R):
+    """40 quads (objects that are one leaf) standing one behind the other, turned so that their boxes are much larger
+    than they are - a ray enters many boxes and misses most quads - plus two objects with trees: the wide kernels let
+    every lane test its own rays' leaf parents nearest box first, 32 at a time, and measure the boxes again when a
+    ray is through with its two nearest. Against the oracle within the bars, on pipelines 3 and 0, in launches of
+    several frames and in single-frame dispatches; reference order bit-exact."""
+    materials = [scenes.mat((0.6, 0.6, 0.6)), scenes.mat((0.8, 0.3, 0.2)), scenes.mat((0.2, 0.6, 0.8)), scenes.mat((0.9, 0.9, 0.9), smoothness=1.0)]
+    objects = [("flat_quad.obj", (0, 0, 0), (0, 0, 0), (40, 40, 40), 0)]
+    for k in range(40):
+        objects.append(("flat_quad.obj", (-3.0 + 0.15 * k + 1.7 * (k % 3), 1.0 + 0.9 * (k % 5), -1.0 - 0.45 * k), (35 + 11 * (k % 7), 20 * k, 45), (1.0 + 0.1 * (k % 4),) * 3, 1 + k % 3))
+    objects.append(("smooth_sphere.obj", (2.5, 1.2, -4.0), (0, 0, 0), (1.2, 1.2, 1.2), 3))
+    objects.append(("cube.obj", (-2.5, 0.8, -6.0), (0, 30, 0), (1.5, 1.5, 1.5), 1))
+    arrays = scenes.build_oracle(materials, objects).bindings()
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(arrays)
+        assert r.get_option(R.RT_INFO_FAST_OBJECTS) == 2
+        W, H = 256, 144
+        opc = scenes.make_pc(arrays, W, H, cam_pos=(0.0, 3.0, 6.0), look=(0.0, -0.12, -1.0), fov=65.0, maxBounces=4, sunDirection=(0.3, -0.8, -0.5))
+        want_acc, want_out = oracle(arrays, opc, [0, 1, 2], W, H)
+        for pipeline in (3, 0):
+            acc, out = render(R, r, opc, [0, 1, 2], W, H, 0, pipeline)
+            assert np.array_equal(bits(acc), bits(want_acc)) and np.array_equal(bits(out), bits(want_out)), pipeline
+            acc, out = render(R, r, opc, [0, 1, 2], W, H, 1, pipeline)
+            same, ok = shares(acc, want_acc)
+            assert ok >= 0.995 and same >= 0.99, (pipeline, same, ok)
+        r.set_option(R.RT_OPT_PIPELINE, 3)
+        r.set_option(R.RT_OPT_TRAVERSAL, 1)
+        r.clear_accumulation()
+        for f in (0, 1, 2):
+            opc["frame"] = f
+            r.render_frame(to_pc(R, opc))
+        same, ok = shares(r.read_image(R.RT_IMAGE_ACCUM), want_acc)
+        assert ok >= 0.995 and same >= 0.99, (same, ok)
+    finally:
+        r.close()
