@@ -126,8 +126,11 @@ enum {
      * with 8 or more objects that own a tree, a hierarchy of such records over the objects' world boxes lets
      * a ray find the objects it crosses nearest first instead of testing every object's box (the reference
      * loops over all of them, raytrace.comp:458-471; the hit is the same, only the order of the tests is
-     * not); 2 = four-child records without that hierarchy; 0 = two-child records. Other pipelines and
-     * mixed scenes always walk two-child records. */
+     * not); 2 = four-child records without that hierarchy; 0 = two-child records. In reference order
+     * (RT_OPT_TRAVERSAL 0) pipeline 3 walks the reference's own trees folded into four-child records whose
+     * slots stand in the reference's visiting order - the same leaves in the same order, bit-identical
+     * images - unless this option is 0. Other pipelines and near-first scenes in which some object keeps the
+     * reference's order always walk two-child records. */
     RT_OPT_WIDE_RECORDS = 20,
     /* Pipeline 3, rt_render_frames launches of more than two frames: 1 = a launch is rendered in pieces of two
      * frames - four times as many, shorter waves, each storing its frames' contributions, which a second small

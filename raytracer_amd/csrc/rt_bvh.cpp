@@ -353,3 +353,79 @@ int32_t rt_build_tlas(const float* boxes, size_t count, bool balanced, std::vect
             if (out[k].ref[c] < 0 && out[k].ref[c] > RT_REF_LIVE_MIN) out[k].ref[c] = RT_REF_INSTANCE + ~out[k].ref[c];
     return root;
 }
+
+// The reference's own two-child records below `root` folded into four-child records WITHOUT changing what a ray hits:
+// the slots of a record stand in the reference's visiting order (first child before second, at every level that is
+// folded away), children that no ray can enter (absent, empty, inverted box) are left out, and an inner child is
+// replaced by its own children in place. A walk that tests a record's slots, descends into the first one hit and stacks
+// the later ones visits the reference's leaves in the reference's order; the box tests it skips (of the children folded
+// away) are implied by the tests of the boxes inside them - a slab interval only grows with the box. Returns the index
+// of the new root record in `out`; `need` = traversal-stack entries a lane can need below it.
+namespace {
+int32_t collapse4_ordered(const std::vector<DevNode>& nodes2, int32_t root, std::vector<DevNode4>& out, int& need)
+{
+    std::vector<Slot4> s;
+    auto take = [&](const DevNode& nd, int c, std::vector<Slot4>& dst, size_t at) {
+        const int32_t ref = c == 0 ? nd.first : nd.second;
+        if (!(ref > RT_REF_LIVE_MIN)) return (size_t)0;
+        Slot4 v;
+        for (int a = 0; a < 3; ++a) { v.lo[a] = nd.lo[a][c]; v.hi[a] = nd.hi[a][c]; }
+        v.ref = ref;
+        dst.insert(dst.begin() + (long)at, v);
+        return (size_t)1;
+    };
+    {
+        const DevNode& nd = nodes2[(size_t)root];
+        size_t at = 0;
+        at += take(nd, 0, s, at);
+        at += take(nd, 1, s, at);
+    }
+    for (;;) {
+        if (s.size() >= 4) break;
+        int pick = -1;
+        float bestArea = -1.0f;
+        for (size_t i = 0; i < s.size(); ++i) {
+            if (s[i].ref < 0) continue;
+            const float dx = s[i].hi[0] - s[i].lo[0], dy = s[i].hi[1] - s[i].lo[1], dz = s[i].hi[2] - s[i].lo[2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (area > bestArea || pick < 0) { bestArea = area; pick = (int)i; }
+        }
+        if (pick < 0) break;
+        const DevNode nd = nodes2[(size_t)s[(size_t)pick].ref];
+        s.erase(s.begin() + pick);
+        size_t at = (size_t)pick;
+        at += take(nd, 0, s, at);
+        at += take(nd, 1, s, at);
+    }
+    const int32_t idx = (int32_t)out.size();
+    out.push_back(DevNode4{});
+    DevNode4 rec{};
+    int below = 0;
+    const int n = (int)s.size();
+    for (int c = 0; c < 4; ++c) {
+        if (c >= n) {
+            for (int a = 0; a < 3; ++a) { rec.lo[a][c] = RT_FAR_PLANE; rec.hi[a][c] = RT_FAR_PLANE; }
+            rec.ref[c] = RT_REF_EMPTY;
+            continue;
+        }
+        for (int a = 0; a < 3; ++a) { rec.lo[a][c] = s[(size_t)c].lo[a]; rec.hi[a][c] = s[(size_t)c].hi[a]; }
+        if (s[(size_t)c].ref >= 0) {
+            int sub = 0;
+            rec.ref[c] = collapse4_ordered(nodes2, s[(size_t)c].ref, out, sub);
+            below = std::max(below, sub);
+        } else {
+            rec.ref[c] = s[(size_t)c].ref;
+        }
+    }
+    out[(size_t)idx] = rec;
+    need = std::max(0, n - 1) + below;
+    return idx;
+}
+} // namespace
+
+int32_t rt_collapse4_ordered(const std::vector<DevNode>& nodes2, int32_t root, std::vector<DevNode4>& out, int& need)
+{
+    need = 0;
+    if (root < 0) return root;
+    return collapse4_ordered(nodes2, root, out, need);
+}

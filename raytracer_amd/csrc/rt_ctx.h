@@ -63,6 +63,14 @@ struct rt_ctx {
     int optTlas = 1;              // wide scenes: hierarchy over the BVH parents' boxes
     int teamWalkers = 4;          // pipeline 4: walker waves per 16-wave workgroup
 
+    // the reference-order scene once more with its trees folded into four-child records in the reference's visiting order
+    // (pipeline 3 only): same objects in the same order, triangles and tables of `scene`, object roots in dRefWideNodes
+    DevScene refWideScene{};
+    void* dRefWideObjects = nullptr;
+    void* dRefWideNodes = nullptr;
+    bool haveRefWide = false;
+    size_t refWideNodeCount = 0;
+
     // images
     int width = 0, height = 0;
     void* ownDraw = nullptr;

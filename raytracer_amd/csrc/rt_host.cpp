@@ -33,6 +33,7 @@ int32_t rt_build_sah(const DevTri* src, size_t count, int maxLeaf, std::vector<D
 void rt_triangle_bounds(const DevTri* src, size_t count, float boundsLo[3], float boundsHi[3]);   // rt_bvh.cpp
 int32_t rt_build_tlas(const float* boxes, size_t count, bool balanced, std::vector<DevNode4>& out, int& need);   // rt_bvh.cpp
 int32_t rt_collapse4(const std::vector<DevNode>& nodes2, int32_t root, std::vector<DevNode4>& out, int& need);   // rt_bvh.cpp
+int32_t rt_collapse4_ordered(const std::vector<DevNode>& nodes2, int32_t root, std::vector<DevNode4>& out, int& need);   // rt_bvh.cpp
 
 extern "C" {
 hipError_t rt_launch_megakernel_strict(const DevScene*, const rt_push_constants*, const DevLaunch*, void*, void*,
@@ -117,7 +118,9 @@ void freeFastScene(rt_ctx* c)
 void freeScene(rt_ctx* c)
 {
     freeFastScene(c);
-    for (void** p : { &c->dObjects, &c->dNodes, &c->dTris, &c->dNrms, &c->dMaterials, &c->dAnyOrder }) {
+    c->haveRefWide = false;
+    c->refWideNodeCount = 0;
+    for (void** p : { &c->dObjects, &c->dNodes, &c->dTris, &c->dNrms, &c->dMaterials, &c->dAnyOrder, &c->dRefWideObjects, &c->dRefWideNodes }) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -784,17 +787,25 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
     // near-first traversal: path tracing on the lock-step kernels only; the counting builds and the debug
     // views always walk the reference's trees in the reference's order
     const DevScene* scene = &ctx->scene;
+    // the two-samples-per-lane kernels render this launch (they are the only ones that walk four-child records)
+    const bool pairKernels = ctx->optPipeline == 3 && pc.renderMode == 0 && !statsOnly && pc.raysPerPixel >= 1 &&
+                             ((long long)frames * pc.raysPerPixel >= 2 || (L.tileSize & 15) == 0);
     if (ctx->optTraversal == 1 && (ctx->optPipeline == 0 || ctx->optPipeline == 3 || ctx->optPipeline == 4) && pc.renderMode == 0 && !statsOnly &&
         pc.parentBVHCount == ctx->scene.objectCount) {
         int rc = ensureFastScene(ctx);
         if (rc != RT_OK) return rc;
         scene = &ctx->fastScene;
-        if (ctx->optWide && ctx->haveWide && ctx->optPipeline == 3 && pc.raysPerPixel >= 1) scene = &ctx->wideScene;
+        if (ctx->optWide && ctx->haveWide && pairKernels) scene = &ctx->wideScene;
+    }
+    if (scene == &ctx->scene && ctx->optWide && ctx->haveRefWide && pairKernels) {
+        // reference order on pipeline 3: the reference's trees folded into four-child records in its visiting order
+        scene = &ctx->refWideScene;
     }
     if (!statsOnly) {
         // shadow rays visit the parents that lie towards the sun first (re-sorted when the sun has moved)
         int rc = refreshAnyOrder(ctx, pc.sunDirection);
         if (rc != RT_OK) return rc;
+        ctx->refWideScene.anyFirst = ctx->scene.anyFirst;       // (the any-hit tables are shared with the reference scene and re-sorted with it)
     }
     if (ctx->optPipeline == 2 && pathTrace && pc.raysPerPixel >= 1 && ctx->scene.objectCount < 65535)   // object indices are packed in 16 bits
         return launchWavefront(ctx, pc, L, statsOnly, countBuild, first, last);
@@ -813,8 +824,7 @@ int launchFrame(rt_ctx* ctx, const rt_push_constants& pc, bool statsOnly, unsign
         // one workgroup of 16 waves per compute unit; its path waves pull tiles from a counter
         auto fn = ctx->optFast ? rt_launch_teamkernel_fast : rt_launch_teamkernel_strict;
         e = fn(scene, &pc, &L, ctx->accum, ctx->draw, ctx->dQueue, std::max(1, ctx->computeUnits), ctx->teamWalkers, ctx->wfRefill, ctx->stream);
-    } else if (ctx->optPipeline == 3 && pc.renderMode == 0 && !statsOnly && pc.raysPerPixel >= 1 &&
-               ((long long)frames * pc.raysPerPixel >= 2 || (L.tileSize & 15) == 0)) {
+    } else if (pairKernels) {
         // two samples of a pixel per lane; a launch that holds one sample per pixel pairs two pixels instead
         auto fn = ctx->optFast ? rt_launch_pairkernel_fast : rt_launch_pairkernel_strict;
         // launches in pieces (RT_OPT_LAUNCH_PIECES): pieces of two frames, their contributions summed in frame order afterwards
@@ -1131,6 +1141,38 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_buffers* b) try
     ctx->triCount = rl.dTris.size();
     ctx->sceneBytes = rl.dObjects.size() * sizeof(DevObject) + rl.dNodes.size() * sizeof(DevNode) + rl.dTris.size() * sizeof(DevTri) +
                       nrms.size() * sizeof(DevNrm) + b->materials.count * sizeof(DevMaterial);
+    // the four-child twin of the reference-order scene (see rt_ctx): every tree folded once, instances of a model share it
+    {
+        std::vector<DevNode4> nodes4;
+        std::vector<DevObject> objects4 = rl.dObjects;
+        std::map<int32_t, std::pair<int32_t, int>> folded;
+        int need = 1;
+        for (DevObject& o : objects4) {
+            if (o.root < 0) continue;
+            auto it = folded.find(o.root);
+            if (it == folded.end()) {
+                int n = 0;
+                const int32_t r4 = rt_collapse4_ordered(rl.dNodes, o.root, nodes4, n);
+                it = folded.emplace(o.root, std::make_pair(r4, n)).first;
+            }
+            o.root = it->second.first;
+            need = std::max(need, it->second.second);
+        }
+        if (!nodes4.empty() && nodes4.size() < (size_t)RT_REF_INSTANCE && need < RT_WIDE_LDS_LEVELS + RT_WIDE_DEEP_LEVELS) {
+            if ((rc = uploadArray(ctx, &ctx->dRefWideObjects, objects4.data(), objects4.size() * sizeof(DevObject))) != RT_OK) return rc;
+            if ((rc = uploadArray(ctx, &ctx->dRefWideNodes, nodes4.data(), nodes4.size() * sizeof(DevNode4))) != RT_OK) return rc;
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DevScene w = ctx->scene;
+            w.objects = static_cast<const DevObject*>(ctx->dRefWideObjects);
+            w.nodes = nullptr;
+            w.nodes4 = static_cast<const DevNode4*>(ctx->dRefWideNodes);
+            w.stackDepth = need + 1;
+            w.wideStackNeed = need;
+            ctx->refWideScene = w;
+            ctx->refWideNodeCount = nodes4.size();
+            ctx->haveRefWide = true;
+        }
+    }
     ctx->hObjects = std::move(rl.dObjects);
     ctx->hFastObjects.clear();
     std::memset(ctx->anyOrderSun, 0xff, sizeof(ctx->anyOrderSun));

@@ -383,6 +383,9 @@ __device__ __noinline__ unsigned visit4_parallel(const DevNode4* node, V3 o, V3 
     return drop;
 }
 
+// SORT = false: the slots stay in the record's order (E = +inf where the ray does not enter), for records whose slots stand in a visiting order
+// that has to be kept.
+template <bool SORT = true>
 __device__ __forceinline__ void visit4(const DevNode4* node, V3 o, V3 inv, bool anyParallel, float tMin, float closest, Visit4& r)
 {
     const float4* np = reinterpret_cast<const float4*>(node);
@@ -424,11 +427,13 @@ __device__ __forceinline__ void visit4(const DevNode4* node, V3 o, V3 inv, bool 
         const int rl_ = sw_ ? rb : ra, rh_ = sw_ ? ra : rb;                         \
         ea = lo_; eb = hi_; ra = rl_; rb = rh_;                                     \
     }
-    RT_CE(e0, r0, e1, r1)
-    RT_CE(e2, r2, e3, r3)
-    RT_CE(e0, r0, e2, r2)
-    RT_CE(e1, r1, e3, r3)
-    RT_CE(e1, r1, e2, r2)
+    if (SORT) {
+        RT_CE(e0, r0, e1, r1)
+        RT_CE(e2, r2, e3, r3)
+        RT_CE(e0, r0, e2, r2)
+        RT_CE(e1, r1, e3, r3)
+        RT_CE(e1, r1, e2, r2)
+    }
 #undef RT_CE
     r.E0 = e0; r.E1 = e1; r.E2 = e2; r.E3 = e3;
     r.R0 = r0; r.R1 = r1; r.R2 = r2; r.R3 = r3;
@@ -1103,7 +1108,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
                 float E;
                 bool ok = (anyPar ? lean_box<true>(org, winv, bmn, bmx, tMin, E) : lean_box<false>(org, winv, bmn, bmx, tMin, E)) && (bw.closest > E);
                 RT_WORK(0, 1);
-                if (!NF && ok) ok = !(distance_to_aabb(org, bmn, bmx) > bw.closest);
+                if ((NF == 0 || NF == 4) && ok) ok = !(distance_to_aabb(org, bmn, bmx) > bw.closest);
                 if (ok) {
                     lo = xform(ob->inv, org, 1.0f);
                     ld = normalize3(xform(ob->inv, dirN, 0.0f));
@@ -1116,6 +1121,62 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
             }
         }
         if (!__any(active)) break;
+        if (NF == 4) {
+            // the reference's trees as four-child records whose slots stand in the reference's visiting order: into the first
+            // slot the ray enters, the later ones stacked so that they come back in order
+            if (cur != RT_NONE) {
+                int budget = RT_DESCENT_CAP4;
+                while ((unsigned)cur < (unsigned)RT_NONE && budget-- > 0) {
+                    Visit4 v;
+                    visit4<false>(S.nodes4 + cur, lo, linv, __any(parL), tMin, bw.closest, v);
+                    const bool h0 = v.E0 < INFINITY, h1 = v.E1 < INFINITY, h2 = v.E2 < INFINITY, h3 = v.E3 < INFINITY;
+                    const bool p1 = h1 && h0, p2 = h2 && (h0 || h1), p3 = h3 && (h0 || h1 || h2);
+                    if (!__any(sp > RT_WIDE_LDS_LEVELS - 3)) {
+                        lds_uint2* slot = wlds + sp * 64;
+                        slot->x = (uint32_t)v.R3; slot->y = __float_as_uint(v.E3);
+                        if (p3) { ++sp; slot += 64; }
+                        slot->x = (uint32_t)v.R2; slot->y = __float_as_uint(v.E2);
+                        if (p2) { ++sp; slot += 64; }
+                        slot->x = (uint32_t)v.R1; slot->y = __float_as_uint(v.E1);
+                        if (p1) ++sp;
+                    } else {
+                        if (p3) wide_push(wlds, wdeep, sp, v.R3, v.E3);
+                        if (p2) wide_push(wlds, wdeep, sp, v.R2, v.E2);
+                        if (p1) wide_push(wlds, wdeep, sp, v.R1, v.E1);
+                    }
+                    cur = h0 ? v.R0 : h1 ? v.R1 : h2 ? v.R2 : v.R3;
+                    if (!(h0 || h1 || h2 || h3)) {
+                        cur = RT_NONE;
+                        while (sp > 0) {
+                            --sp;
+                            const uint2 e = wide_top(wlds, wdeep, sp);
+                            if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                        }
+                    }
+                }
+                if (cur < 0) {      // at a leaf (a lane whose descent was cut short goes on in the next round)
+                    bool stop = false;
+                    const float4* tp = reinterpret_cast<const float4*>(S.tris + ~cur);
+                    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    for (;;) {
+                        tp += 3;
+                        const float4 n0 = tp[0], n1 = tp[1], n2 = tp[2];
+                        const int remaining = __float_as_int(t0.w);
+                        if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, obj, bw) && ANYHIT) { stop = true; break; }
+                        if (remaining <= 1) break;
+                        t0 = n0; t1 = n1; t2 = n2;
+                    }
+                    cur = RT_NONE;
+                    if (stop) sp = 0;
+                    while (sp > 0) {
+                        --sp;
+                        const uint2 e = wide_top(wlds, wdeep, sp);
+                        if (bw.closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                    }
+                }
+            }
+            continue;
+        }
         if (NF == 2) {
             if (cur != RT_NONE) {
                 int budget = RT_DESCENT_CAP4;
@@ -1418,7 +1479,8 @@ __device__ __forceinline__ void walls_pair(const DevScene& S, int base, int coun
 // leaf parents first, a ray stops at its first accepted hit.
 // NF: 0 = the reference-order scene (near-first handling compiled out); 1 = the scene holds rebuilt two-child trees
 // (DevScene::nearFirstBase set); 2 = wide scene, four-child records, parents found box by box; 3 = wide scene with the
-// hierarchy over the parents (walk_tlas_pair).
+// hierarchy over the parents (walk_tlas_pair); 4 = the reference-order scene with its trees folded into four-child records
+// whose slots stand in the reference's visiting order (same hits, bit for bit).
 template <bool ANYHIT, int NF>
 __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V3 oA, V3 dA, bool onA, Best& bA, V3 oB, V3 dB, bool onB,
                                            Best& bB, float tMin, float tMax, uint2* stack)
@@ -1430,9 +1492,9 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
     V3 winvA, winvB;
     const bool parWA = lean_inverse(dA, winvA) && onA, parWB = lean_inverse(dB, winvB) && onB;
     const bool permute = ANYHIT && parentCount == S.objectCount;
-    const bool tightScene = NF != 0;   // the near-first scene: boxes are only culls
+    const bool tightScene = NF != 0 && NF != 4;   // the near-first scene: boxes are only culls
     int pos = 0;
-    if (NF >= 2 && RT_LANE_WALLS) {
+    if ((NF == 2 || NF == 3) && RT_LANE_WALLS) {
         // a wide scene stores its leaf parents first (in both orders): every lane goes through its own rays' walls, nearest first
         RT_SEC_BEGIN(secWall);
         for (; pos < S.anyLeafCount; pos += 32) {
@@ -1458,7 +1520,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
             // consecutive BVH parents (up to 64): RT_RUN_MIN or more are walked lane by lane
             int count = permute ? S.runLenAny[pos] : S.runLen[pos];
             count = count < parentCount - pos ? count : parentCount - pos;
-            if (count >= (NF == 2 ? 1 : RT_RUN_MIN)) {      // (four-child records are only walked by the run walker)
+            if (count >= (NF == 2 || NF == 4 ? 1 : RT_RUN_MIN)) {      // (four-child records are only walked by the run walker)
                 RT_SEC_BEGIN(secRun);
                 walk_run_pair<ANYHIT, NF>(S, permute, pos, count, oA, dA, winvA, liveA, bA, oB, dB, winvB, liveB, bB, __any(parWA || parWB), tMin, stack);
                 RT_SEC_END(ANYHIT ? 6 : 3, secRun);
@@ -1466,7 +1528,7 @@ __device__ __forceinline__ void trace_pair(const DevScene& S, int parentCount, V
                 continue;
             }
         }
-        if (NF >= 2 && RT_LANE_WALLS) continue;      // not reached: leaf parents were handled above, BVH parents in runs or under the hierarchy
+        if ((NF == 2 || NF == 3) && RT_LANE_WALLS) continue;      // not reached: leaf parents were handled above, BVH parents in runs or under the hierarchy
         RT_WORK(0, (liveA ? 1 : 0) + (liveB ? 1 : 0));
         const V3 bmn = ld3(ob->bmin), bmx = ld3(ob->bmax);
         float E;
@@ -3240,7 +3302,12 @@ extern "C" hipError_t RT_SYM(rt_launch_pairkernel)(const DevScene* S, const rt_p
     // <true> knows rebuilt trees (near-first traversal), <false> has that handling compiled out
     // <2> walks four-child records (the wide twin of an order-free near-first scene)
     // <3> walks them from the hierarchy over the parents' boxes (wide scenes with many BVH parents)
-    const bool nf = S->nearFirstBase != 0x7fffffff, wide = S->nodes4 != nullptr, tlas = wide && S->tlasRoot != RT_REF_EMPTY;
+    const bool nf = S->nearFirstBase != 0x7fffffff, wide = S->nodes4 != nullptr && nf, tlas = wide && S->tlasRoot != RT_REF_EMPTY;
+    // <4> walks the reference's trees folded into four-child records, in the reference's order
+    const bool refWide = S->nodes4 != nullptr && !nf;
+    if (refWide && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<4>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
+    else if (refWide) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<4>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out, (float4*)partial);
+    else
     if (tlas && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<3>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);
     else if (tlas) hipLaunchKernelGGL(RT_SYM(rt_pairkernel)<3>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out, (float4*)partial);
     else if (wide && pixelPairs) hipLaunchKernelGGL(RT_SYM(rt_pixelpairkernel)<2>, grid, block, lds, stream, *S, *pc, *L, (float4*)accum, (float4*)out);

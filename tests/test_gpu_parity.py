@@ -357,6 +357,34 @@ def test_deepest_tree_the_stack_allows(R, tmp_path):
         r.close()
 
 
+def test_reference_order_on_folded_records(R, default_scene_arrays):
+    """Pipeline 3 walks the reference's trees folded into four-child records whose slots stand in the reference's
+    visiting order (RT_OPT_WIDE_RECORDS 1, the default) or the two-child records themselves (0): the same image, the
+    oracle's, bit for bit - on the default scene and on the scene with every material class, shrunk and stretched
+    objects, a model without normals and one with a 287-triangle leaf; multi-frame launches and single-frame dispatches."""
+    materials, objects = scenes.mixed_recipe()
+    mixed = scenes.build_oracle(materials, objects).bindings()
+    for arrays, cam in ((default_scene_arrays, {}), (mixed, dict(cam_pos=(0.0, 2.5, 8.0), look=(0.0, -0.15, -1.0), fov=60.0, maxBounces=5))):
+        W, H = 208, 120
+        opc = scenes.make_pc(arrays, W, H, **cam)
+        want = oracle_frames(arrays, opc, [0, 1, 2, 3, 4], W, H)
+        r = R.Renderer(0)
+        try:
+            r.upload_scene(arrays)
+            r.set_option(R.RT_OPT_PIPELINE, 3)
+            for wide in (1, 0):
+                r.set_option(R.RT_OPT_WIDE_RECORDS, wide)
+                acc, out = gpu_frames(R, r, opc, [0, 1, 2, 3, 4], W, H)
+                assert np.array_equal(bits(acc), bits(want["accum"])) and np.array_equal(bits(out), bits(want["out"])), wide
+                r.clear_accumulation()
+                for f in range(5):
+                    opc["frame"] = f
+                    r.render_frame(to_pc(R, opc))
+                assert np.array_equal(bits(r.read_image(R.RT_IMAGE_ACCUM)), bits(want["accum"])), wide
+        finally:
+            r.close()
+
+
 def test_empty_scene_is_all_sky(R):
     arrays = [np.zeros(0, d) for d in O.BINDING_DTYPES]
     r = R.Renderer(0)
