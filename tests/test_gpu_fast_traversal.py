@@ -351,3 +351,31 @@ def test_many_leaf_parents_every_lane_for_itself(R):
         assert ok >= 0.995 and same >= 0.99, (same, ok)
     finally:
         r.close()
+
+
+def test_single_frame_dispatch_with_a_tile_size_that_is_no_multiple_of_16(R, default_scene_arrays):
+    """rt_render_frame pairs two rows of pixels per lane, which needs tiles of whole 16-row bands; with another tile size
+    the single-frame dispatch is rendered by kernel 0, which walks two-child records - in both flavours (the four-child
+    scenes are for the pair kernels only)."""
+    W, H = 200, 120
+    opc = scenes.make_pc(default_scene_arrays, W, H)
+    want_acc, want_out = oracle(default_scene_arrays, opc, [0, 1], W, H)
+    r = R.Renderer(0)
+    try:
+        r.upload_scene(default_scene_arrays)
+        r.resize(W, H)
+        r.set_option(R.RT_OPT_TILE_SIZE, 24)
+        for traversal in (0, 1):
+            r.set_option(R.RT_OPT_TRAVERSAL, traversal)
+            r.clear_accumulation()
+            for f in (0, 1):
+                opc["frame"] = f
+                r.render_frame(to_pc(R, opc))
+            acc = r.read_image(R.RT_IMAGE_ACCUM)
+            if traversal == 0:
+                assert np.array_equal(bits(acc), bits(want_acc))
+            else:
+                same, ok = shares(acc, want_acc)
+                assert ok >= 0.995 and same >= 0.999, (same, ok)
+    finally:
+        r.close()
