@@ -516,6 +516,9 @@ __device__ __forceinline__ bool triangle_hit(float4 t0, float4 t1, float4 t2, V3
 #ifndef RT_DESCENT_CAP
 #define RT_DESCENT_CAP 6
 #endif
+#ifndef RT_PREFETCH_ALL
+#define RT_PREFETCH_ALL 0     /* 1: the record behind a leaf's last triangle is fetched as well (unconditional fetch-ahead) */
+#endif
 #ifndef RT_DESCENT_CAP4
 #define RT_DESCENT_CAP4 3   /* the same cut for walks of four-child records */
 #endif
@@ -1159,9 +1162,10 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
                     const float4* tp = reinterpret_cast<const float4*>(S.tris + ~cur);
                     float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                     for (;;) {
-                        tp += 3;
-                        const float4 n0 = tp[0], n1 = tp[1], n2 = tp[2];
+                        // (only lanes whose leaf goes on fetch ahead: the address units are the busiest part of the memory path)
                         const int remaining = __float_as_int(t0.w);
+                        float4 n0 = t0, n1 = t1, n2 = t2;
+                        if (RT_PREFETCH_ALL || remaining > 1) { tp += 3; n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }
                         if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, obj, bw) && ANYHIT) { stop = true; break; }
                         if (remaining <= 1) break;
                         t0 = n0; t1 = n1; t2 = n2;
@@ -1214,9 +1218,10 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
                     const float4* tp = reinterpret_cast<const float4*>(S.tris + ~cur);
                     float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                     for (;;) {
-                        tp += 3;
-                        const float4 n0 = tp[0], n1 = tp[1], n2 = tp[2];
+                        // (only lanes whose leaf goes on fetch ahead: the address units are the busiest part of the memory path)
                         const int remaining = __float_as_int(t0.w);
+                        float4 n0 = t0, n1 = t1, n2 = t2;
+                        if (RT_PREFETCH_ALL || remaining > 1) { tp += 3; n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }
                         if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, obj, bw) && ANYHIT) { stop = true; break; }
                         if (remaining <= 1) break;
                         t0 = n0; t1 = n1; t2 = n2;
@@ -1368,9 +1373,9 @@ __device__ __forceinline__ void walk_tlas_pair(const DevScene& S, V3 oA, V3 dA, 
             const float4* tp = reinterpret_cast<const float4*>(S.tris + ~cur);
             float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
             for (;;) {
-                tp += 3;
-                const float4 n0 = tp[0], n1 = tp[1], n2 = tp[2];
                 const int remaining = __float_as_int(t0.w);
+                float4 n0 = t0, n1 = t1, n2 = t2;
+                if (RT_PREFETCH_ALL || remaining > 1) { tp += 3; n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }
                 if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, obj, bw) && ANYHIT) { stop = true; break; }
                 if (remaining <= 1) break;
                 t0 = n0; t1 = n1; t2 = n2;
