@@ -109,7 +109,7 @@ enum {
      * 0 (default) = the reference's trees in the reference's order (left child first,
      * raytrace.comp:603-604): results bit-identical to the CPU oracle. 1 = near-first: every object whose
      * transform shrinks nothing walks a tree rebuilt at first use (binned surface-area heuristic, tight
-     * boxes, at most RT_OPT_SAH_MAX_LEAF triangles per leaf, default 4), the nearer child first, children
+     * boxes, at most RT_OPT_SAH_MAX_LEAF triangles per leaf, default 2), the nearer child first, children
      * behind the closest hit dropped; every object gets a tight world box. The hit GetHit returns is the
      * triangle with the smallest world-space distance in either order, so the images differ only where two
      * triangles tie exactly (shared edges): within the stated tolerance (>= 99.5 % of pixels within

@@ -49,7 +49,7 @@ struct rt_ctx {
     bool haveFast = false;
     int fastObjects = 0;          // objects that walk a rebuilt tree
     size_t fastNodeCount = 0, fastTriCount = 0;
-    int optTraversal = 0, sahMaxLeaf = 4;
+    int optTraversal = 0, sahMaxLeaf = 2;
     // the wide twin of an order-free near-first scene (four-child records, pipeline 3 only): same object
     // boxes, triangles and any-hit tables as fastScene, object roots in dWideNodes
     DevScene wideScene{};
