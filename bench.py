@@ -421,6 +421,9 @@ def main():
                         "flops_per_launch": (21.0 * cw["box_tests"] + 45.0 * cw["triangle_tests"]) * k,
                         "bytes_per_launch": (40.0 * cw["box_tests"] + 48.0 * cw["triangle_tests"]) * k + 48.0 * pixels_rank * frames_rank / launches,
                         "counted_by": "raytracer_amd/librt_amd_count.so (the timed kernels with work counters), %d frames, untimed" % cf}
+                if cw.get("lane_share"):
+                    # share of a wave's 64 lanes that work where the wave passes (walks of four-child records only)
+                    done["lane_share_in_walks"] = cw["lane_share"]
                 done["tflops"] = done["flops_per_launch"] / (launch_ms * 1e-3) / 1e12
                 done["gbps"] = done["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
         ref_equiv = {"flops_per_launch": flops_per_launch, "bytes_per_launch": bytes_per_launch, "tflops": alg_tflops, "gbps": alg_gbps,

@@ -46,15 +46,21 @@
 // only knows the reference's). Every lane adds into its own LDS word; a wave adds its sums to g_workCounters
 // when it ends; rt_debug_work_counters() reads and clears them.
 #ifdef RT_WORK_COUNTERS
-__device__ unsigned long long g_workCounters[4];     // 0 box tests, 1 triangle tests, 2 GetHit calls, 3 record fetches
-__device__ __noinline__ unsigned* rt_work_lds() { __shared__ unsigned a[4 * 64]; return a; }
+// 0 box tests, 1 triangle tests, 2 GetHit calls, 3 record fetches; lane slots offered / used (RT_WORK_LANES: 64 per wave that
+// passes, 1 per lane that is active there): 4 / 5 four-child visits, 6 / 7 triangle tests of the walks' leaves, 8 / 9 walls
+// tested lane by lane
+#define RT_WORK_SLOTS 10
+__device__ unsigned long long g_workCounters[RT_WORK_SLOTS];
+__device__ __noinline__ unsigned* rt_work_lds() { __shared__ unsigned a[RT_WORK_SLOTS * 64]; return a; }
 #define RT_WORK(k, n) do { rt_work_lds()[(k) * 64 + (threadIdx.x & 63)] += (unsigned)(n); } while (0)
-#define RT_WORK_BEGIN() do { unsigned* a_ = rt_work_lds(); for (int k_ = 0; k_ < 4; ++k_) a_[k_ * 64 + (threadIdx.x & 63)] = 0; } while (0)
+#define RT_WORK_LANES(k) do { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) RT_WORK(k, 64); RT_WORK((k) + 1, 1); } while (0)
+#define RT_WORK_BEGIN() do { unsigned* a_ = rt_work_lds(); for (int k_ = 0; k_ < RT_WORK_SLOTS; ++k_) a_[k_ * 64 + (threadIdx.x & 63)] = 0; } while (0)
 #define RT_WORK_END() do { const unsigned* a_ = rt_work_lds(); \
         if ((int)threadIdx.x == __ffsll((long long)__ballot(true)) - 1) \
-            for (int k_ = 0; k_ < 4; ++k_) { unsigned long long s_ = 0; for (int l_ = 0; l_ < 64; ++l_) s_ += a_[k_ * 64 + l_]; atomicAdd(&g_workCounters[k_], s_); } } while (0)
+            for (int k_ = 0; k_ < RT_WORK_SLOTS; ++k_) { unsigned long long s_ = 0; for (int l_ = 0; l_ < 64; ++l_) s_ += a_[k_ * 64 + l_]; atomicAdd(&g_workCounters[k_], s_); } } while (0)
 #else
 #define RT_WORK(k, n) do { } while (0)
+#define RT_WORK_LANES(k) do { } while (0)
 #define RT_WORK_BEGIN() do { } while (0)
 #define RT_WORK_END() do { } while (0)
 #endif
@@ -1187,6 +1193,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
                 while ((unsigned)cur < (unsigned)RT_NONE && budget-- > 0) {
                     Visit4 v;
                     visit4(S.nodes4 + cur, lo, linv, __any(parL), tMin, bw.closest, v);
+                    RT_WORK_LANES(4);
                     if (!__any(sp > RT_WIDE_LDS_LEVELS - 3)) {
                         // the usual case, without branches: every entry is written to the lane's next free slot and
                         // the slot is kept only if the child is to be visited
@@ -1222,6 +1229,7 @@ __device__ __forceinline__ void walk_run_pair(const DevScene& S, bool permute, i
                         const int remaining = __float_as_int(t0.w);
                         float4 n0 = t0, n1 = t1, n2 = t2;
                         if (RT_PREFETCH_ALL || remaining > 1) { tp += 3; n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }
+                        RT_WORK_LANES(6);
                         if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, obj, bw) && ANYHIT) { stop = true; break; }
                         if (remaining <= 1) break;
                         t0 = n0; t1 = n1; t2 = n2;
@@ -1336,6 +1344,7 @@ __device__ __forceinline__ void walk_tlas_pair(const DevScene& S, V3 oA, V3 dA, 
             const V3 ro = top ? org : lo, ri = top ? winv : linv;
             Visit4 v;
             visit4(S.nodes4 + cur, ro, ri, anyParW || __any(parL), tMin, bw.closest, v);
+            RT_WORK_LANES(4);
             if (!__any(sp > RT_WIDE_LDS_LEVELS - 3)) {
                 lds_uint2* slot = wlds + sp * 64;
                 slot->x = (uint32_t)v.R3; slot->y = __float_as_uint(v.E3);
@@ -1376,6 +1385,7 @@ __device__ __forceinline__ void walk_tlas_pair(const DevScene& S, V3 oA, V3 dA, 
                 const int remaining = __float_as_int(t0.w);
                 float4 n0 = t0, n1 = t1, n2 = t2;
                 if (RT_PREFETCH_ALL || remaining > 1) { tp += 3; n0 = tp[0]; n1 = tp[1]; n2 = tp[2]; }
+                RT_WORK_LANES(6);
                 if (triangle_hit(t0, t1, t2, lo, ld, ob->fwd, org, dirN, tMin, obj, bw) && ANYHIT) { stop = true; break; }
                 if (remaining <= 1) break;
                 t0 = n0; t1 = n1; t2 = n2;
@@ -1411,6 +1421,7 @@ template <bool ANYHIT>
 __device__ __forceinline__ void wall_step(const DevScene& S, int base, WallRay& w, V3 org, V3 dirN, float tMin, Best& best)
 {
     const DevObject* ob = S.objects + base + w.k;      // per lane
+    RT_WORK_LANES(8);
     const V3 lo = xform(ob->inv, org, 1.0f), ld = normalize3(xform(ob->inv, dirN, 0.0f));
     const float4* tp = reinterpret_cast<const float4*>(S.tris + ~ob->root);
     bool hit = false;
@@ -3258,10 +3269,10 @@ extern "C" int rt_debug_sections(unsigned long long out[8])
 
 #if defined(RT_WORK_COUNTERS) && defined(RT_FLAVOUR_STRICT)
 // reads and clears the work counters of the strict flavour's two-samples-per-lane kernels (the device must be idle)
-extern "C" int rt_debug_work_counters(unsigned long long out[4])
+extern "C" int rt_debug_work_counters(unsigned long long out[RT_WORK_SLOTS])
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_workCounters), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    unsigned long long zero[4] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_workCounters), RT_WORK_SLOTS * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long zero[RT_WORK_SLOTS] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_workCounters), zero, sizeof(zero)) != hipSuccess) return -1;
     return 0;
 }

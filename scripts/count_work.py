@@ -19,7 +19,7 @@ r.resize(wl["width"], wl["height"])
 r.set_option(R.RT_OPT_PIPELINE, 3)
 r.set_option(R.RT_OPT_TRAVERSAL, trav)
 lib = R.load_library()
-out = (C.c_uint64 * 4)()
+out = (C.c_uint64 * 10)()
 r.sync()
 if lib.rt_debug_work_counters(out) != 0:
     raise SystemExit("rt_debug_work_counters failed")
@@ -28,4 +28,8 @@ r.sync()
 if lib.rt_debug_work_counters(out) != 0:
     raise SystemExit("rt_debug_work_counters failed")
 print(json.dumps({"config": config, "traversal": trav, "frames": frames, "box_tests": int(out[0]), "triangle_tests": int(out[1]),
-                  "rays": int(out[2]), "record_fetches": int(out[3])}))
+                  "rays": int(out[2]), "record_fetches": int(out[3]),
+                  # share of the lanes that are active where a wave passes (near-first kernels on four-child records)
+                  "lane_share": {"visits": round(out[5] / max(1, out[4]), 4), "leaf_triangles": round(out[7] / max(1, out[6]), 4),
+                                 "walls": round(out[9] / max(1, out[8]), 4)},
+                  "lane_slots": {"visits": int(out[4]), "leaf_triangles": int(out[6]), "walls": int(out[8])}}))
